@@ -69,8 +69,11 @@ class SpotConfig:
 
 
 FULL = SpotConfig()
-# Reduced configuration used by fast tests (fixture G2).
+# Reduced configuration used by the CPU-only oracle tests (fixture G2).
 TINY = SpotConfig(channels=8, encoder_channels=64, ffw_dim=32)
+# Smallest configuration the MFMA tiles accept (channel widths multiples of 64):
+# two levels, bottleneck width 128 (head_dim 16).  Used by fast GPU parity tests.
+SMALL = SpotConfig(stride_list=(2, 4), channels=64, encoder_channels=128, ffw_dim=128)
 
 
 def spot_param_shapes(cfg: SpotConfig):

@@ -1,0 +1,41 @@
+// Shared host-side helpers for libasw_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/asw_hip.h"
+
+namespace asw {
+
+// thread-local error message returned by asw_last_error()
+char* err_buf();
+int set_error(int code, const char* fmt, ...);
+
+#define ASW_CHECK_ARG(cond, ...)                                   \
+  do {                                                             \
+    if (!(cond)) return ::asw::set_error(ASW_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define ASW_HIP(call)                                                                 \
+  do {                                                                                \
+    hipError_t _e = (call);                                                           \
+    if (_e != hipSuccess)                                                             \
+      return ::asw::set_error(ASW_ERR_HIP, "%s failed: %s (%s:%d)", #call,            \
+                              hipGetErrorString(_e), __FILE__, __LINE__);             \
+  } while (0)
+
+#define ASW_LAUNCH_CHECK()                                                            \
+  do {                                                                                \
+    hipError_t _e = hipGetLastError();                                                \
+    if (_e != hipSuccess)                                                             \
+      return ::asw::set_error(ASW_ERR_HIP, "kernel launch failed: %s (%s:%d)",        \
+                              hipGetErrorString(_e), __FILE__, __LINE__);             \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace asw

@@ -1,0 +1,286 @@
+// convgemm.hip -- 1-D conv / transposed conv / linear as implicit GEMM on the gfx950
+// f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain), with the layer's
+// element-wise tail fused into the epilogue.
+//
+// Replaces (reference file:line): DilatedResidualLayer conv+ReLU+residual+LayerNorm
+// (sep/training/SpeakerLocalization/network.py:57-68), EncoderBlock.conv1
+// (:105-108), UpsamplerBlock ConvTranspose1d (:158-165,190), mask_encoder /
+// reference_bypass / output_decoder contraction (:327-349,397-402) and the
+// transformer linears (:254).
+//
+// Layout: activations channels-last [B][T][C] fp32, weights Wt[N][K] with
+// K = tap*Cin + c.  One workgroup (256 threads = 4 waves) owns a BM x BN output tile
+// of one batch item; K is walked in chunks of BK channels of one tap.  A and W chunks
+// are staged global -> registers -> LDS (row stride BK+4 floats: the ds_read_b128
+// fragment reads below are then bank-conflict free), the next chunk's global loads
+// are in flight while the MFMAs of the current chunk run.
+//
+// MFMA operand order: for v_mfma_f32_32x32x2_f32 lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31].  A lane reads 4 consecutive k (one b128) at column
+// kk*8 + 4*(l>>5) of its row; step s of 4 uses element s of both operands, so the
+// logical k visited by (step s, half h) is kk*8 + 4h + s for A and B alike -- any
+// consistent permutation of k is a valid GEMM.
+//
+// Epilogue: the accumulators of one 32-row slab are written to LDS (C/D map:
+// col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)), then each wave owns whole
+// rows: + residual, * gate tensor, LayerNorm over the row (two-pass, wave shuffles),
+// GroupNorm partial sums, coalesced row stores.
+#include "asw_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS>
+__global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int LDK = BK + 4;
+  constexpr int KV = BK / 4;                 // float4 per staged row
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_VEC = (BM * KV + 255) / 256, B_VEC = (BN * KV + 255) / 256;
+  constexpr int LDC = BN + 4;
+  constexpr int NQ = BN / 64;
+
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+  float* Ct = smem;                          // epilogue slab, reuses the staging area
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int K = p.taps * p.Cin;
+  const int cpb = p.Cin / BK;                // chunks per tap
+  const int nk = p.taps * cpb;
+  const float* __restrict__ Ab = p.A + (long)b * p.a_batch_stride;
+  const float* __restrict__ A2b = p.A2 ? p.A2 + (long)b * p.a_batch_stride : nullptr;
+
+  float4 ra[A_VEC], rb[B_VEC];
+
+  auto gload = [&](int kc) {
+    const int tap = kc / cpb;
+    const int c0 = (kc - tap * cpb) * BK;
+#pragma unroll
+    for (int v = 0; v < A_VEC; ++v) {
+      const int idx = tid + v * 256;
+      const int row = idx / KV, cv = idx - row * KV;
+      const int t_out = m0 + row;
+      const long e = ((long)t_out * p.stride + (long)tap * p.dil - p.pad) * p.a_row_stride + c0 + cv * 4;
+      const bool ok = (idx < BM * KV) && (t_out < p.M_out) && (e >= 0) && (e + 3 < p.a_len);
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        x = *reinterpret_cast<const float4*>(Ab + e);
+        if (A2b) {
+          const float4 y = *reinterpret_cast<const float4*>(A2b + e);
+          x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        }
+      }
+      ra[v] = x;
+    }
+#pragma unroll
+    for (int v = 0; v < B_VEC; ++v) {
+      const int idx = tid + v * 256;
+      const int row = idx / KV, cv = idx - row * KV;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < BN * KV && n0 + row < p.N)
+        x = *reinterpret_cast<const float4*>(p.Wt + (long)(n0 + row) * K + (long)kc * BK + cv * 4);
+      rb[v] = x;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int v = 0; v < A_VEC; ++v) {
+      const int idx = tid + v * 256;
+      const int row = idx / KV, cv = idx - row * KV;
+      if (idx < BM * KV) *reinterpret_cast<float4*>(As + row * LDK + cv * 4) = ra[v];
+    }
+#pragma unroll
+    for (int v = 0; v < B_VEC; ++v) {
+      const int idx = tid + v * 256;
+      const int row = idx / KV, cv = idx - row * KV;
+      if (idx < BN * KV) *reinterpret_cast<float4*>(Bs + row * LDK + cv * 4) = rb[v];
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* a_rd = As + (wm * (BM / WM) + (lane & 31)) * LDK + (lane >> 5) * 4;
+  const float* b_rd = Bs + (wn * (BN / WN) + (lane & 31)) * LDK + (lane >> 5) * 4;
+
+  gload(0);
+  for (int kc = 0; kc < nk; ++kc) {
+    __syncthreads();                  // previous chunk's fragment reads are done
+    lstore();
+    __syncthreads();
+    if (kc + 1 < nk) gload(kc + 1);   // in flight under the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_rd + i * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_rd + j * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float a = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float bb = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  float st0 = 0.f, sq0 = 0.f, st1 = 0.f, sq1 = 0.f;
+  const int half_mod = p.chan_mod >> 1;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = wn * (BN / WN) + tn * 32 + (lane & 31);
+      const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[tm][tn][r] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        Ct[row * LDC + col] = v;
+      }
+    }
+    __syncthreads();
+    for (int sr = wid; sr < WM * 32; sr += 4) {
+      const int trow = (sr >> 5) * (BM / WM) + tm * 32 + (sr & 31);
+      const int t_out = m0 + trow;
+      if (t_out >= p.M_out) continue;           // wave-uniform
+      const long obase = ((long)b * p.M_out + t_out) * p.N + n0;
+      float v[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int col = lane + 64 * q;
+        float x = Ct[sr * LDC + col];
+        if (p.resid) x += p.resid[obase + col];
+        if (p.mul) x *= p.mul[obase + col];
+        v[q] = x;
+      }
+      if (LN) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s += v[q];
+        const float mean = wave_sum(s) * (1.0f / BN);
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { const float c = v[q] - mean; d += c * c; }
+        const float var = wave_sum(d) * (1.0f / BN);
+        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int col = lane + 64 * q;
+          v[q] = (v[q] - mean) * rstd * p.ln_gamma[col] + p.ln_beta[col];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int col = lane + 64 * q;
+        if (STATS) {
+          const bool g1 = ((n0 + col) % p.chan_mod) >= half_mod;
+          const float x = v[q];
+          if (g1) { st1 += x; sq1 += x * x; } else { st0 += x; sq0 += x * x; }
+        }
+        p.out[obase + col] = v[q];
+      }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    st0 = wave_sum(st0); sq0 = wave_sum(sq0); st1 = wave_sum(st1); sq1 = wave_sum(sq1);
+    float* red = smem;                           // Ct is dead after the barrier above
+    if (lane == 0) { red[wid * 4 + 0] = st0; red[wid * 4 + 1] = sq0; red[wid * 4 + 2] = st1; red[wid * 4 + 3] = sq1; }
+    __syncthreads();
+    if (tid < 4) {
+      const float s = red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
+      const long part = ((long)b * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y;
+      p.stats[part * 4 + tid] = s;
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS>
+int launch(const asw_convgemm_args& a, hipStream_t s) {
+  constexpr int LDK = BK + 4;
+  constexpr size_t stage = (size_t)(BM + BN) * LDK * sizeof(float);
+  constexpr size_t slab = (size_t)(WM * 32) * (BN + 4) * sizeof(float);
+  constexpr size_t smem = stage > slab ? stage : slab;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  auto kern = convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  ASW_CHECK_ARG(a.Cin % BK == 0, "convgemm: Cin=%d not a multiple of BK=%d", a.Cin, BK);
+  ASW_CHECK_ARG(a.N % BN == 0, "convgemm: N=%d not a multiple of BN=%d", a.N, BN);
+  dim3 grid(asw::cdiv(a.M_out, BM), a.N / BN, a.B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+// tile choice for the non-LayerNorm variants; must match asw_convgemm_stats_tiles
+inline bool wide_tile(int N) { return N % 128 == 0; }
+
+}  // namespace
+
+extern "C" int asw_convgemm_stats_tiles(int M_out, int N) {
+  if (wide_tile(N)) return asw::cdiv(M_out, 128) * (N / 128);
+  return asw::cdiv(M_out, 256) * (N / 64);
+}
+
+extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
+  ASW_CHECK_ARG(args != nullptr, "convgemm: null args");
+  const asw_convgemm_args& a = *args;
+  hipStream_t s = asw::as_stream(stream);
+  ASW_CHECK_ARG(a.A && a.Wt && a.out, "convgemm: null tensor");
+  ASW_CHECK_ARG(a.B > 0 && a.M_out > 0 && a.N > 0 && a.Cin > 0 && a.taps > 0, "convgemm: bad dims");
+  ASW_CHECK_ARG(a.a_row_stride % 4 == 0 && a.a_batch_stride % 4 == 0 && a.a_len % 4 == 0 && a.Cin % 4 == 0,
+                "convgemm: strides must be multiples of 4 floats");
+  ASW_CHECK_ARG(a.B <= 65535, "convgemm: batch %d exceeds grid.z", a.B);
+  const bool stats = a.stats != nullptr;
+  if (stats) ASW_CHECK_ARG(a.chan_mod >= 2 && a.chan_mod % 2 == 0, "convgemm: stats need even chan_mod");
+  if (a.ln_gamma) {
+    ASW_CHECK_ARG(a.ln_beta != nullptr, "convgemm: LayerNorm needs beta");
+    ASW_CHECK_ARG(!stats, "convgemm: LayerNorm + stats epilogue is not a reference layer");
+    switch (a.N) {
+      case 64: return launch<256, 64, 32, 4, 1, true, false>(a, s);
+      case 128: return launch<128, 128, 32, 2, 2, true, false>(a, s);
+      case 256: return launch<64, 256, 32, 1, 4, true, false>(a, s);
+      case 512: return launch<64, 512, 16, 1, 4, true, false>(a, s);
+      case 1024: return launch<32, 1024, 16, 1, 4, true, false>(a, s);
+      default:
+        return asw::set_error(ASW_ERR_ARG, "convgemm: LayerNorm width %d unsupported (64..1024, power of 2)", a.N);
+    }
+  }
+  if (wide_tile(a.N)) {
+    return stats ? launch<128, 128, 32, 2, 2, false, true>(a, s) : launch<128, 128, 32, 2, 2, false, false>(a, s);
+  }
+  ASW_CHECK_ARG(a.N % 64 == 0, "convgemm: N=%d must be a multiple of 64", a.N);
+  return stats ? launch<256, 64, 32, 4, 1, false, true>(a, s) : launch<256, 64, 32, 4, 1, false, false>(a, s);
+}

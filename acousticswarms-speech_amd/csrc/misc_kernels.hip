@@ -1,0 +1,366 @@
+// misc_kernels.hip -- the memory-bound / small kernels around the MFMA GEMMs.
+#include "asw_common.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm(2) + GLU.  EncoderBlock / DecoderBlock tail
+// (sep/training/SpeakerLocalization/network.py:107-113,194-197).  With 2 groups over
+// 2C channels, group 0 is exactly the GLU value half and group 1 the gate half.
+// Statistics arrive as per-tile partial sums from the producing GEMM's epilogue and are
+// reduced here in double (deterministic, no atomics).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_glu_kernel(const float* __restrict__ raw, const float* __restrict__ stats,
+                                                     int n_partials, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int T, int C, float eps,
+                                                     float* __restrict__ out, int items_per_block) {
+  __shared__ double red[4][4];
+  __shared__ float mr[4];                 // mean0, rstd0, mean1, rstd1
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double s[4] = {0, 0, 0, 0};
+  const float* sp = stats + (long)b * n_partials * 4;
+  for (int i = threadIdx.x; i < n_partials; i += blockDim.x) {
+    const float4 v = *reinterpret_cast<const float4*>(sp + (long)i * 4);
+    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s[k] = wave_sum_d(s[k]);
+    if (lane == 0) red[wid][k] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int g = threadIdx.x;
+    const double cnt = (double)T * (double)C;
+    const double sum = red[0][2 * g] + red[1][2 * g] + red[2][2 * g] + red[3][2 * g];
+    const double sq = red[0][2 * g + 1] + red[1][2 * g + 1] + red[2][2 * g + 1] + red[3][2 * g + 1];
+    const double mean = sum / cnt;
+    double var = sq / cnt - mean * mean;   // biased, as nn.GroupNorm
+    if (var < 0) var = 0;
+    mr[2 * g] = (float)mean;
+    mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float m0 = mr[0], r0 = mr[1], m1 = mr[2], r1 = mr[3];
+  const int c4n = C >> 2;
+  const long total = (long)T * c4n;
+  const long i0 = (long)blockIdx.x * items_per_block;
+  const long i1 = i0 + items_per_block < total ? i0 + items_per_block : total;
+  const float* rb = raw + (long)b * T * 2 * C;
+  float* ob = out + (long)b * T * C;
+  for (long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const long t = i / c4n;
+    const int c = (int)(i - t * c4n) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(rb + t * 2 * C + c);
+    const float4 g = *reinterpret_cast<const float4*>(rb + t * 2 * C + C + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), ba = *reinterpret_cast<const float4*>(beta + c);
+    const float4 gg = *reinterpret_cast<const float4*>(gamma + C + c), bg = *reinterpret_cast<const float4*>(beta + C + c);
+    float4 o;
+#define ASW_GLU(f)                                              \
+  {                                                             \
+    const float av = (a.f - m0) * r0 * ga.f + ba.f;             \
+    const float gv = (g.f - m1) * r1 * gg.f + bg.f;             \
+    o.f = av / (1.0f + expf(-gv));                              \
+  }
+    ASW_GLU(x) ASW_GLU(y) ASW_GLU(z) ASW_GLU(w)
+#undef ASW_GLU
+    *reinterpret_cast<float4*>(ob + t * C + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Self-attention core (nn.MultiheadAttention inside nn.TransformerEncoderLayer,
+// network.py:254): per (batch, head, 16-query tile) a flash-style sweep over 128-key
+// tiles held in LDS, online softmax, fp32 VALU.  The bottleneck is 1-4 % of the
+// forward's FLOPs (sequence T/256 = 188 or 563), so this kernel is written for
+// exactness and bounded LDS rather than MFMA rate.
+// thread = (query q = tid/16, sub-lane sl = tid%16): scores for keys sl+16*jj,
+// output dims sl+16*i.
+// ---------------------------------------------------------------------------
+constexpr int ATT_BQ = 16, ATT_KT = 128, ATT_MAXD = 8;   // head_dim <= 128
+
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, int L, int d, int nhead,
+                                                        float* __restrict__ ctx) {
+  extern __shared__ __align__(16) float smem[];
+  const int hd = d / nhead;
+  const int ldk = hd + 1;
+  float* Qs = smem;                       // [BQ][hd+1]
+  float* Ks = Qs + ATT_BQ * ldk;          // [KT][hd+1]
+  float* Vs = Ks + ATT_KT * ldk;          // [KT][hd]
+  float* Ps = Vs + ATT_KT * hd;           // [BQ][KT]
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * ATT_BQ;
+  const int tid = threadIdx.x, q = tid >> 4, sl = tid & 15;
+  const float* base = qkv + (long)b * L * 3 * d;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int nd = hd >> 4;                 // output dims per thread
+
+  for (int i = tid; i < ATT_BQ * hd; i += 256) {
+    const int r = i / hd, c = i - r * hd;
+    Qs[r * ldk + c] = (q0 + r < L) ? base[(long)(q0 + r) * 3 * d + h * hd + c] * scale : 0.f;
+  }
+  float acc[ATT_MAXD];
+#pragma unroll
+  for (int i = 0; i < ATT_MAXD; ++i) acc[i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int k0 = 0; k0 < L; k0 += ATT_KT) {
+    const int kn = L - k0 < ATT_KT ? L - k0 : ATT_KT;
+    __syncthreads();                      // previous tile fully consumed (also covers Qs)
+    for (int i = tid; i < ATT_KT * hd; i += 256) {
+      const int r = i / hd, c = i - r * hd;
+      float kv = 0.f, vv = 0.f;
+      if (r < kn) {
+        const float* row = base + (long)(k0 + r) * 3 * d + h * hd + c;
+        kv = row[d];
+        vv = row[2 * d];
+      }
+      Ks[r * ldk + c] = kv;
+      Vs[r * hd + c] = vv;
+    }
+    __syncthreads();
+    // scores for this thread's keys
+    float sc[ATT_KT / 16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < ATT_KT / 16; ++jj) {
+      const int j = sl + 16 * jj;
+      float s = 0.f;
+      for (int c = 0; c < hd; ++c) s = fmaf(Qs[q * ldk + c], Ks[j * ldk + c], s);
+      sc[jj] = (j < kn) ? s : -INFINITY;
+      tmax = fmaxf(tmax, sc[jj]);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < ATT_KT / 16; ++jj) {
+      const float pv = (sc[jj] == -INFINITY) ? 0.f : expf(sc[jj] - m_new);
+      Ps[q * ATT_KT + sl + 16 * jj] = pv;
+      psum += pv;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ATT_MAXD; ++i) acc[i] *= alpha;
+    for (int j = 0; j < kn; ++j) {
+      const float pv = Ps[q * ATT_KT + j];
+#pragma unroll
+      for (int i = 0; i < ATT_MAXD; ++i)
+        if (i < nd) acc[i] = fmaf(pv, Vs[j * hd + sl + 16 * i], acc[i]);
+    }
+  }
+  if (q0 + q < L) {
+    const float inv = 1.0f / l_run;
+    float* o = ctx + ((long)b * L + q0 + q) * d + h * hd;
+#pragma unroll
+    for (int i = 0; i < ATT_MAXD; ++i)
+      if (i < nd) o[sl + 16 * i] = acc[i] * inv;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// output_decoder ConvTranspose1d(E->1, k=taps, stride=hop) as overlap-add of the
+// per-frame tap products D[b][f][j] (computed by a GEMM), trim [trim_left : ...], keep
+// the last t samples (network.py:400-405), then y*std+mean (JointModel/network.py:96).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ D, int F, int ldd, int taps,
+                                                          int hop, int T_pad, int t, int trim_left, float bias,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t) return;
+  const int u = i + (T_pad - t) + trim_left;    // index into the untrimmed ConvTranspose output
+  float s = bias;
+  const float* Db = D + (long)b * F * ldd;
+  for (int j = u % hop; j < taps; j += hop) {
+    const int f = (u - j) / hop;
+    if (f >= 0 && f < F) s += Db[(long)f * ldd + j];
+  }
+  if (mean) s = s * stdv[b] + mean[b];
+  out[(long)b * t + i] = s;
+}
+
+// ---------------------------------------------------------------------------
+// Candidate energies (sep/helpers/local_utils_3d.py:13-17,349-354; Mic_Array.py:290-295):
+// x = y - mean(y); power = sum x^2; power2 = max_i sqrt(|mean(x^2[i:i+W])|) with zeros
+// past the end.  One workgroup per candidate; the prefix sum of x^2 goes through a
+// global scratch row (double) so window sums are c[min(i+W,T)] - c[i].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void energy_kernel(const float* __restrict__ y, int T, int window,
+                                                      double* __restrict__ scratch, double* __restrict__ out) {
+  __shared__ double red[16];
+  __shared__ double scan[1024];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* yb = y + (long)b * T;
+  double* c = scratch + (long)b * (T + 1);
+  double acc = 0.0;
+  for (int i = tid; i < T; i += 1024) acc += (double)yb[i];
+  acc = wave_sum_d(acc);
+  if (lane == 0) red[wid] = acc;
+  __syncthreads();
+  double tot = 0.0;
+  for (int i = 0; i < 16; ++i) tot += red[i];
+  const float mu = (float)(tot / (double)T);     // np.mean of a float32 row is float32
+  // contiguous chunk per thread
+  const int chunk = (T + 1023) / 1024;
+  const int s0 = tid * chunk, s1 = s0 + chunk < T ? s0 + chunk : T;
+  double part = 0.0;
+  for (int i = s0; i < s1; ++i) { const float x = yb[i] - mu; part += (double)(x * x); }
+  scan[tid] = part;
+  __syncthreads();
+  // inclusive Hillis-Steele scan over 1024 partials
+  for (int o = 1; o < 1024; o <<= 1) {
+    const double v = tid >= o ? scan[tid - o] : 0.0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  double run = tid == 0 ? 0.0 : scan[tid - 1];
+  const double total = scan[1023];
+  if (tid == 0) c[0] = 0.0;
+  for (int i = s0; i < s1; ++i) { const float x = yb[i] - mu; run += (double)(x * x); c[i + 1] = run; }
+  __syncthreads();                               // same-workgroup global visibility
+  double best = 0.0;
+  for (int i = tid; i < T; i += 1024) {
+    const int hi = i + window < T ? i + window : T;
+    const double w = fabs((c[hi] - c[i]) / (double)window);
+    best = w > best ? w : best;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double v = __shfl_xor(best, o, 64); best = v > best ? v : best; }
+  __syncthreads();
+  if (lane == 0) red[wid] = best;
+  __syncthreads();
+  if (tid == 0) {
+    double m = 0.0;
+    for (int i = 0; i < 16; ++i) m = red[i] > m ? red[i] : m;
+    out[b * 2 + 0] = total;
+    out[b * 2 + 1] = sqrt(m);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// SI-SDR of every ordered pair (sep/helpers/eval_utils.py:11-39): block (i=est, j=ref).
+// pass 1: <s,s>, <s,e>; pass 2: |a s|^2, |e - a s|^2 with the reference's float32
+// element arithmetic and double accumulation.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_sisdr_kernel(const float* __restrict__ y, int T,
+                                                         double* __restrict__ out) {
+  __shared__ double red[4][2];
+  const int i = blockIdx.x, j = blockIdx.y, n = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* e = y + (long)i * T;
+  const float* s = y + (long)j * T;
+  double a0 = 0, a1 = 0;
+  for (int t = tid; t < T; t += 256) { a0 += (double)(s[t] * s[t]); a1 += (double)(s[t] * e[t]); }
+  a0 = wave_sum_d(a0); a1 = wave_sum_d(a1);
+  if (lane == 0) { red[wid][0] = a0; red[wid][1] = a1; }
+  __syncthreads();
+  const float rss = (float)(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+  const float rse = (float)(red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+  const float a = rse / rss;
+  __syncthreads();
+  double b0 = 0, b1 = 0;
+  for (int t = tid; t < T; t += 256) {
+    const float tr = a * s[t];
+    const float rs = e[t] - tr;
+    b0 += (double)(tr * tr);
+    b1 += (double)(rs * rs);
+  }
+  b0 = wave_sum_d(b0); b1 = wave_sum_d(b1);
+  if (lane == 0) { red[wid][0] = b0; red[wid][1] = b1; }
+  __syncthreads();
+  if (tid == 0) {
+    const double sss = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    const double snn = red[0][1] + red[1][1] + red[2][1] + red[3][1] + 1e-8;
+    out[(long)i * n + j] = 10.0 * log10(sss / snn);
+  }
+}
+
+}  // namespace
+
+extern "C" int asw_gn_glu(const float* raw, const float* stats, int n_partials, const float* gamma,
+                          const float* beta, int B, int T, int C, float eps, float* out, void* stream) {
+  ASW_CHECK_ARG(raw && stats && gamma && beta && out, "gn_glu: null pointer");
+  ASW_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && n_partials > 0, "gn_glu: bad shape");
+  const int items = 256 * 8;
+  dim3 grid(asw::cdiv((long)T * (C / 4), items), B);
+  hipLaunchKernelGGL(gn_glu_kernel, grid, dim3(256), 0, asw::as_stream(stream), raw, stats, n_partials, gamma, beta,
+                     T, C, eps, out, items);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+extern "C" int asw_attention(const float* qkv, int B, int L, int d, int nhead, float* ctx, void* stream) {
+  ASW_CHECK_ARG(qkv && ctx, "attention: null pointer");
+  ASW_CHECK_ARG(B > 0 && L > 0 && nhead > 0 && d % nhead == 0, "attention: bad shape");
+  const int hd = d / nhead;
+  ASW_CHECK_ARG(hd % 16 == 0 && hd <= 16 * ATT_MAXD, "attention: head_dim %d must be a multiple of 16, <= 128", hd);
+  ASW_CHECK_ARG(B <= 65535 && nhead <= 65535, "attention: grid too large");
+  const size_t smem = sizeof(float) * ((size_t)ATT_BQ * (hd + 1) + (size_t)ATT_KT * (hd + 1) + (size_t)ATT_KT * hd +
+                                       (size_t)ATT_BQ * ATT_KT);
+  static size_t smem_set = 0;
+  if (smem > smem_set) {
+    ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    smem_set = smem;
+  }
+  dim3 grid(asw::cdiv(L, ATT_BQ), nhead, B);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), smem, asw::as_stream(stream), qkv, L, d, nhead, ctx);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+extern "C" int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int taps, int hop, int T_pad, int t,
+                                      int trim_left, float bias, const float* mean, const float* std, float* out,
+                                      void* stream) {
+  ASW_CHECK_ARG(D && out, "overlap_add: null pointer");
+  ASW_CHECK_ARG(B > 0 && F > 0 && taps > 0 && taps <= ldd && hop > 0 && t > 0 && T_pad >= t, "overlap_add: bad shape");
+  ASW_CHECK_ARG((mean == nullptr) == (std == nullptr), "overlap_add: mean/std must both be given or both NULL");
+  ASW_CHECK_ARG(B <= 65535, "overlap_add: batch too large");
+  dim3 grid(asw::cdiv(t, 256), B);
+  hipLaunchKernelGGL(overlap_add_kernel, grid, dim3(256), 0, asw::as_stream(stream), D, F, ldd, taps, hop, T_pad, t,
+                     trim_left, bias, mean, std, out);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+extern "C" int asw_energies(const float* y, int B, int T, int window, double* scratch, double* out, void* stream) {
+  ASW_CHECK_ARG(y && scratch && out, "energies: null pointer");
+  ASW_CHECK_ARG(T > 0 && window > 0, "energies: bad shape");
+  if (B == 0) return ASW_OK;
+  hipLaunchKernelGGL(energy_kernel, dim3(B), dim3(1024), 0, asw::as_stream(stream), y, T, window, scratch, out);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+extern "C" int asw_pair_sisdr(const float* y, int n, int T, double* out, void* stream) {
+  ASW_CHECK_ARG(y && out, "pair_sisdr: null pointer");
+  ASW_CHECK_ARG(n > 0 && n <= 65535 && T > 0, "pair_sisdr: bad shape");
+  hipLaunchKernelGGL(pair_sisdr_kernel, dim3(n, n), dim3(256), 0, asw::as_stream(stream), y, T, out);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}

@@ -1,0 +1,135 @@
+"""ctypes binding of libasw_hip.so (the C ABI declared in include/asw_hip.h).
+
+The library is the only implementation of the hot path: there is no CPU or
+PyTorch fallback.  ``lib()`` raises if the shared object is missing, and every
+wrapper raises ``RuntimeError`` with ``asw_last_error()`` on a non-zero status.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_long, c_size_t, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasw_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["asw_common.cpp", "convgemm.hip", "prep_kernels.hip", "misc_kernels.hip", "srp_kernels.hip",
+           "spot_model.hip"]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into libasw_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "asw_common.h"),
+                   os.path.join(os.path.dirname(_HERE), "include", "asw_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+class SpotConfigC(Structure):
+    _fields_ = [("n_mics", c_int32), ("kernel_size", c_int32), ("depth", c_int32),
+                ("stride_list", c_int32 * 8), ("channels", c_int32), ("growth", c_int32),
+                ("encoder_channels", c_int32), ("encoder_kernel_size", c_int32),
+                ("encoder_stride", c_int32), ("residual_layers", c_int32),
+                ("residual_dilation_factor", c_int32), ("num_head", c_int32), ("ffw_dim", c_int32),
+                ("num_transformer_layers", c_int32)]
+
+    @classmethod
+    def from_config(cls, cfg):
+        s = cls()
+        s.n_mics, s.kernel_size, s.depth = cfg.n_mics, cfg.kernel_size, cfg.depth
+        for i, v in enumerate(cfg.stride_list):
+            s.stride_list[i] = v
+        s.channels, s.growth = cfg.channels, int(cfg.growth)
+        s.encoder_channels, s.encoder_kernel_size = cfg.encoder_channels, cfg.encoder_kernel_size
+        s.encoder_stride, s.residual_layers = cfg.encoder_stride, cfg.residual_layers
+        s.residual_dilation_factor, s.num_head = cfg.residual_dilation_factor, cfg.num_head
+        s.ffw_dim, s.num_transformer_layers = cfg.ffw_dim, cfg.num_transformer_layers
+        return s
+
+
+class ConvGemmArgs(Structure):
+    _fields_ = [("A", c_void_p), ("A2", c_void_p), ("Wt", c_void_p), ("bias", c_void_p),
+                ("resid", c_void_p), ("mul", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p),
+                ("out", c_void_p), ("stats", c_void_p),
+                ("B", c_int32), ("M_out", c_int32), ("N", c_int32), ("Cin", c_int32), ("taps", c_int32),
+                ("stride", c_int32), ("dil", c_int32), ("pad", c_int32), ("a_row_stride", c_int32),
+                ("a_batch_stride", c_int64), ("a_len", c_int64), ("chan_mod", c_int32), ("relu", c_int32),
+                ("ln_eps", c_float)]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/asw_hip.h
+SIGNATURES = {
+    "asw_last_error": (c_char_p, []),
+    "asw_abi_version": (c_int, []),
+    "asw_spot_create": (c_int, [POINTER(SpotConfigC), POINTER(c_void_p)]),
+    "asw_spot_destroy": (None, [c_void_p]),
+    "asw_spot_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    "asw_spot_finalize": (c_int, [c_void_p]),
+    "asw_spot_set_batch": (c_int, [c_void_p, c_int]),
+    "asw_spot_shift_and_sep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_int, c_void_p]),
+    "asw_spot_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p, c_void_p]),
+    "asw_spot_get_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]),
+    "asw_shift_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "asw_shift_norm_preproc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p]),
+    "asw_pad_preproc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                c_void_p, c_long, c_void_p]),
+    "asw_convgemm_f32": (c_int, [POINTER(ConvGemmArgs), c_void_p]),
+    "asw_convgemm_stats_tiles": (c_int, [c_int, c_int]),
+    "asw_gn_glu": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                           c_void_p]),
+    "asw_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "asw_overlap_add_unnorm": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "asw_energies": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "asw_pair_sisdr": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "asw_srp_frames": (c_int, [c_int, c_int, c_int]),
+    "asw_srp_cross_spectra": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "asw_srp_map": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libasw_hip.so (fail loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int):
+    if status != 0:
+        msg = lib().asw_last_error()
+        raise RuntimeError(f"libasw_hip: status {status}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,119 @@
+"""Thin tensor-level wrappers over the individual C-ABI kernels (include/asw_hip.h).
+
+Used by the parity tests (each kernel against the oracle) and by the host code of the
+SRP-PHAT and clustering stages.  Tensors are torch CUDA tensors used purely as device
+buffers; every function launches on torch's current stream.
+"""
+from ctypes import byref
+
+import torch
+
+from . import native
+from .native import ConvGemmArgs, check, current_stream, lib, ptr
+
+
+def _f32(t):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "need contiguous float32 CUDA tensor"
+    return t
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """torch Conv1d weight [N, Cin, K] -> Wt [N, K*Cin] (k-major, channel fastest)."""
+    N, Cin, K = w.shape
+    return w.permute(0, 2, 1).reshape(N, K * Cin).contiguous()
+
+
+def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, relu=False, resid=None, mul=None,
+             ln=None, stats_chan_mod=0, A2=None, B=None, a_row_stride=None, a_batch_stride=None, a_len=None,
+             out=None, ln_eps=1e-5):
+    """out[b][r][n] per include/asw_hip.h:asw_convgemm_f32.  Returns (out, stats|None)."""
+    _f32(A); _f32(Wt)
+    if B is None:
+        B = A.shape[0]
+    a_row_stride = Cin if a_row_stride is None else a_row_stride
+    if a_batch_stride is None:
+        a_batch_stride = A[0].numel()
+    if a_len is None:
+        a_len = a_batch_stride
+    if out is None:
+        out = torch.empty((B, M_out, N), dtype=torch.float32, device=A.device)
+    stats = None
+    if stats_chan_mod:
+        tiles = lib().asw_convgemm_stats_tiles(M_out, N)
+        stats = torch.zeros((B, tiles, 4), dtype=torch.float32, device=A.device)
+    a = ConvGemmArgs()
+    a.A, a.A2, a.Wt = A.data_ptr(), (A2.data_ptr() if A2 is not None else None), Wt.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.resid = resid.data_ptr() if resid is not None else None
+    a.mul = mul.data_ptr() if mul is not None else None
+    a.ln_gamma = ln[0].data_ptr() if ln is not None else None
+    a.ln_beta = ln[1].data_ptr() if ln is not None else None
+    a.out = out.data_ptr()
+    a.stats = stats.data_ptr() if stats is not None else None
+    a.B, a.M_out, a.N, a.Cin, a.taps, a.stride, a.dil, a.pad = B, M_out, N, Cin, taps, stride, dil, pad
+    a.a_row_stride, a.a_batch_stride, a.a_len = a_row_stride, a_batch_stride, a_len
+    a.chan_mod, a.relu, a.ln_eps = stats_chan_mod, int(relu), ln_eps
+    check(lib().asw_convgemm_f32(byref(a), current_stream()))
+    return out, stats
+
+
+def gn_glu(raw, stats, gamma, beta, eps=1e-5):
+    B, T, C2 = raw.shape
+    C = C2 // 2
+    out = torch.empty((B, T, C), dtype=torch.float32, device=raw.device)
+    check(lib().asw_gn_glu(ptr(_f32(raw)), ptr(_f32(stats)), stats.shape[1], ptr(_f32(gamma)), ptr(_f32(beta)),
+                           B, T, C, eps, ptr(out), current_stream()))
+    return out
+
+
+def attention(qkv, nhead):
+    B, L, d3 = qkv.shape
+    d = d3 // 3
+    ctx = torch.empty((B, L, d), dtype=torch.float32, device=qkv.device)
+    check(lib().asw_attention(ptr(_f32(qkv)), B, L, d, nhead, ptr(ctx), current_stream()))
+    return ctx
+
+
+def shift_stats(mix, offsets, circular=True):
+    M, T = mix.shape
+    N = offsets.shape[0]
+    mean = torch.empty((N,), dtype=torch.float32, device=mix.device)
+    std = torch.empty((N,), dtype=torch.float32, device=mix.device)
+    check(lib().asw_shift_stats(ptr(_f32(mix)), M, T, ptr(offsets), N, int(circular), ptr(mean), ptr(std),
+                                current_stream()))
+    return mean, std
+
+
+def shift_norm_preproc(mix, offsets, mean, std, w, b, T_pad, circular=True):
+    M, T = mix.shape
+    N = offsets.shape[0]
+    C = w.shape[0]
+    x0 = torch.empty((N, T_pad, C), dtype=torch.float32, device=mix.device)
+    refn = torch.zeros((N, T_pad), dtype=torch.float32, device=mix.device)
+    check(lib().asw_shift_norm_preproc(ptr(_f32(mix)), M, T, T_pad, ptr(offsets), N, int(circular), ptr(mean),
+                                       ptr(std), ptr(_f32(w)), ptr(_f32(b)), C, ptr(x0), ptr(refn), T_pad,
+                                       current_stream()))
+    return x0, refn
+
+
+def overlap_add_unnorm(D, taps, hop, T_pad, t, trim_left, bias, mean=None, std=None):
+    B, F, ldd = D.shape
+    out = torch.empty((B, t), dtype=torch.float32, device=D.device)
+    check(lib().asw_overlap_add_unnorm(ptr(_f32(D)), B, F, ldd, taps, hop, T_pad, t, trim_left, float(bias),
+                                       ptr(mean), ptr(std), ptr(out), current_stream()))
+    return out
+
+
+def energies(y, window=12000):
+    B, T = y.shape
+    scratch = torch.empty((B, T + 1), dtype=torch.float64, device=y.device)
+    out = torch.empty((B, 2), dtype=torch.float64, device=y.device)
+    check(lib().asw_energies(ptr(_f32(y)), B, T, window, ptr(scratch), ptr(out), current_stream()))
+    return out
+
+
+def pair_sisdr(y):
+    n, T = y.shape
+    out = torch.empty((n, n), dtype=torch.float64, device=y.device)
+    check(lib().asw_pair_sisdr(ptr(_f32(y)), n, T, ptr(out), current_stream()))
+    return out

@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference's spot-model call surface over libasw_hip.so.
+
+``SpotModel`` keeps the names, argument meaning and return types of
+``DataParallelSpotModel.shift_and_sep`` (sep/training/JointModel/network.py:27-104) and
+``Network.forward`` (sep/training/SpeakerLocalization/network.py:363-405); all
+arithmetic runs in the HIP library.  PyTorch is used only for device memory and
+streams.  ``shift_and_score`` is the additive energies-only fast path:
+waveforms stay on the GPU, two doubles per candidate come back.
+"""
+from collections import OrderedDict
+from ctypes import byref, c_float, c_size_t, c_void_p
+
+import numpy as np
+
+from . import native
+from .config import FULL, SpotConfig, spot_param_shapes
+
+
+def offsets_from_patches(patch_list, n_pairs: int) -> np.ndarray:
+    """round(sample_offset) per candidate as int32 [N, M-1]
+    (JointModel/network.py:81-82: torch.round is round-half-even == np.rint)."""
+    if len(patch_list) == 0:
+        return np.zeros((0, n_pairs), dtype=np.int32)
+    offs = np.stack([np.asarray(getattr(p, "sample_offset", p), dtype=np.float64) for p in patch_list])
+    if offs.shape[1] != n_pairs:
+        raise RuntimeError(f"candidate has {offs.shape[1]} offsets, mixture has {n_pairs + 1} channels")
+    return np.rint(offs).astype(np.int32)
+
+
+class SpotModel:
+    def __init__(self, cfg: SpotConfig = FULL, state_dict=None, batch_size: int = 32):
+        self.cfg = cfg
+        self.batch_size = batch_size
+        self.device = None
+        self._h = None
+        self._sd = None
+        self.last_waveforms = None          # device tensor [N,T] of the latest shift_and_score
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    # ---- weights -------------------------------------------------------------
+    def load_state_dict(self, sd, strict: bool = True):
+        """Reference-format state dict (numpy arrays or torch tensors)."""
+        want = OrderedDict(spot_param_shapes(self.cfg))
+        clean = OrderedDict()
+        for k, v in sd.items():
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            clean[k] = np.ascontiguousarray(a, dtype=np.float32)
+        missing = [k for k in want if k not in clean]
+        extra = [k for k in clean if k not in want]
+        if strict and (missing or extra):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:3]} unexpected {extra[:3]}")
+        for k, shp in want.items():
+            if k in clean and tuple(clean[k].shape) != tuple(shp):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(clean[k].shape)} vs {tuple(shp)}")
+        self._sd = clean
+        if self._h is not None:
+            self._upload()
+        return self
+
+    def _upload(self):
+        L = native.lib()
+        for k, a in self._sd.items():
+            native.check(L.asw_spot_set_param(self._h, k.encode(), c_void_p(a.ctypes.data), a.size))
+        native.check(L.asw_spot_finalize(self._h))
+
+    def to(self, device=None):
+        """Create the device-resident model (weights uploaded once; C1 of SURVEY.md §2.2)."""
+        import torch
+        if device is None:
+            return self
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("SpotModel runs only on an MI355X (device 'cuda'); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the spot hot path has no CPU fallback")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(device)
+        L = native.lib()
+        if self._h is not None:
+            L.asw_spot_destroy(self._h)
+            self._h = None
+        h = c_void_p()
+        cc = native.SpotConfigC.from_config(self.cfg)
+        native.check(L.asw_spot_create(byref(cc), byref(h)))
+        self._h = h
+        native.check(L.asw_spot_set_batch(self._h, int(self.batch_size)))
+        self.device = device
+        if self._sd is not None:
+            self._upload()
+        return self
+
+    def eval(self):
+        return self
+
+    def set_batch_size(self, b: int):
+        self.batch_size = int(b)
+        if self._h is not None:
+            native.check(native.lib().asw_spot_set_batch(self._h, int(b)))
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                native.lib().asw_spot_destroy(self._h)
+        except Exception:
+            pass
+
+    def _need(self):
+        if self._h is None:
+            raise RuntimeError("SpotModel.to('cuda') must be called before inference")
+        if self._sd is None:
+            raise RuntimeError("SpotModel has no weights: call load_state_dict()")
+
+    # ---- device-level entry (tensors stay on the GPU) --------------------------
+    def shift_and_sep_device(self, mix_dev, offsets_dev, strict: int = 0, want_wave: bool = True,
+                             want_energy: bool = False, window: int = 12000, circular: bool = True):
+        """mix_dev [M,T] float32 cuda, offsets_dev [N,M-1] int32 cuda ->
+        (wave [N,T] float32 cuda | None, energy [N,2] float64 cuda | None)."""
+        import torch
+        self._need()
+        M, T = mix_dev.shape
+        N = offsets_dev.shape[0]
+        assert mix_dev.dtype == torch.float32 and mix_dev.is_contiguous() and mix_dev.is_cuda
+        assert offsets_dev.dtype == torch.int32 and offsets_dev.is_contiguous() and offsets_dev.is_cuda
+        wave = torch.empty((N, T), dtype=torch.float32, device=mix_dev.device) if want_wave else None
+        en = torch.empty((N, 2), dtype=torch.float64, device=mix_dev.device) if want_energy else None
+        if N > 0:
+            with torch.cuda.device(mix_dev.device):
+                native.check(native.lib().asw_spot_shift_and_sep(
+                    self._h, native.ptr(mix_dev), M, T, native.ptr(offsets_dev), N, int(strict), int(circular),
+                    native.ptr(wave), native.ptr(en), int(window), native.current_stream()))
+        return wave, en
+
+    # ---- reference call surface ---------------------------------------------------
+    def shift_and_sep(self, input_channels, patch_list, Strict: int = 0, save_input: bool = False) -> np.ndarray:
+        """Drop-in for DataParallelSpotModel.shift_and_sep: returns ndarray [N,T] float32."""
+        import torch
+        self._need()
+        if save_input:
+            raise RuntimeError("save_input=True is a debugging path of the reference that materialises every "
+                               "shifted mixture; it is not provided (the shifted tensor never exists here)")
+        mix = torch.as_tensor(input_channels)
+        T = mix.shape[-1]
+        if len(patch_list) == 0:
+            return np.empty((0, T), dtype=np.float32)
+        offs = offsets_from_patches(patch_list, mix.shape[0] - 1)
+        mix_d = mix.to(self.device, dtype=torch.float32).contiguous()
+        off_d = torch.from_numpy(offs).to(self.device)
+        wave, _ = self.shift_and_sep_device(mix_d, off_d, Strict, want_wave=True)
+        return wave.cpu().numpy()
+
+    def shift_and_score(self, input_channels, patch_list, Strict: int = 0, window: int = 12000,
+                        keep_waveforms: bool = True) -> np.ndarray:
+        """Energies-only fast path: ndarray [N,2] float64 = (power, power2) of every
+        mean-removed candidate output (local_utils_3d.py:349-354 / Mic_Array.py:290-295)."""
+        import torch
+        self._need()
+        mix = torch.as_tensor(input_channels)
+        if len(patch_list) == 0:
+            self.last_waveforms = None
+            return np.empty((0, 2), dtype=np.float64)
+        offs = offsets_from_patches(patch_list, mix.shape[0] - 1)
+        mix_d = mix.to(self.device, dtype=torch.float32).contiguous()
+        off_d = torch.from_numpy(offs).to(self.device)
+        wave, en = self.shift_and_sep_device(mix_d, off_d, Strict, want_wave=keep_waveforms, want_energy=True,
+                                             window=window)
+        self.last_waveforms = wave
+        return en.cpu().numpy()
+
+    def forward(self, mix, window_embedding):
+        """Network.forward: mix [B,M,t] (already normalised), window_embedding [B,2] -> [B,1,t]
+        (device tensor).  Rows are grouped by identical embedding because the window gate
+        is folded into the convolution weights."""
+        import torch
+        self._need()
+        mix = torch.as_tensor(mix).to(self.device, dtype=torch.float32).contiguous()
+        wemb = torch.as_tensor(window_embedding, dtype=torch.float32).cpu().numpy().reshape(mix.shape[0], 2)
+        B, M, t = mix.shape
+        out = torch.empty((B, 1, t), dtype=torch.float32, device=self.device)
+        L = native.lib()
+        keys = {}
+        for i, row in enumerate(map(tuple, wemb)):
+            keys.setdefault(row, []).append(i)
+        with torch.cuda.device(self.device):
+            for row, idx in keys.items():
+                whole = len(idx) == B
+                x = mix if whole else mix[idx].contiguous()
+                y = out.view(B, t) if whole else torch.empty((len(idx), t), dtype=torch.float32, device=self.device)
+                w = (c_float * 2)(float(row[0]), float(row[1]))
+                native.check(L.asw_spot_forward(self._h, native.ptr(x), len(idx), M, t, w, native.ptr(y),
+                                                native.current_stream()))
+                if not whole:
+                    out.view(B, t)[idx] = y
+        return out
+
+    __call__ = forward
+
+    def get_tap(self, name: str, shape=None):
+        """Intermediate activation of the last forward (channels-last), for parity tests."""
+        import torch
+        n = c_size_t()
+        L = native.lib()
+        native.check(L.asw_spot_get_tap(self._h, name.encode(), None, 0, byref(n), None))
+        buf = torch.empty((n.value,), dtype=torch.float32, device=self.device)
+        native.check(L.asw_spot_get_tap(self._h, name.encode(), native.ptr(buf), n.value, byref(n),
+                                        native.current_stream()))
+        return buf if shape is None else buf.view(*shape)

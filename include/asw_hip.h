@@ -1,0 +1,210 @@
+/*
+ * asw_hip.h -- C ABI of libasw_hip.so: the MI355X (gfx950) implementation of the
+ * Spotforming localization-by-separation hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes (device
+ * pointers unless a parameter says "host"), enqueues its work on the given HIP
+ * stream (hipStream_t passed as void*; NULL = default stream) and returns 0 or a
+ * negative asw_status.  No exception crosses the ABI; asw_last_error() returns a
+ * thread-local message for the last failure.  Inputs are borrowed and never
+ * mutated; outputs are caller-owned buffers.
+ *
+ * Each function cites the reference interface (file:line under the upstream
+ * repo) it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ */
+#ifndef ASW_HIP_H
+#define ASW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum asw_status {
+  ASW_OK = 0,
+  ASW_ERR_ARG = -1,       /* bad shape / null pointer / unsupported configuration */
+  ASW_ERR_HIP = -2,       /* a HIP runtime call failed                             */
+  ASW_ERR_NOMEM = -3,     /* device allocation failed                              */
+  ASW_ERR_STATE = -4      /* handle used before weights were loaded                */
+} asw_status;
+
+const char* asw_last_error(void);
+int asw_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Spot-network hyper-parameters.  Mirrors Network.__init__
+ * (sep/training/SpeakerLocalization/network.py:268-292).
+ * ---------------------------------------------------------------------- */
+typedef struct asw_spot_config {
+  int32_t n_mics;                 /* 7 */
+  int32_t kernel_size;            /* 7 */
+  int32_t depth;                  /* len(stride_list) <= 8 */
+  int32_t stride_list[8];         /* 2,2,4,4,4 */
+  int32_t channels;               /* 64 */
+  int32_t growth;                 /* 2 */
+  int32_t encoder_channels;       /* 2048 */
+  int32_t encoder_kernel_size;    /* 33 */
+  int32_t encoder_stride;         /* 16 */
+  int32_t residual_layers;        /* 3 */
+  int32_t residual_dilation_factor; /* 7 */
+  int32_t num_head;               /* 8 */
+  int32_t ffw_dim;                /* 1024 */
+  int32_t num_transformer_layers; /* 2 */
+} asw_spot_config;
+
+typedef struct asw_spot asw_spot;   /* opaque: device-resident weights + workspace */
+
+/* Create a model for `cfg` on the current HIP device.  Replaces Network(**model_params)
+ * + .to(device) (sep/helpers/utils.py:176-183, sep/training/base_network.py:41-45). */
+int asw_spot_create(const asw_spot_config* cfg, asw_spot** out);
+void asw_spot_destroy(asw_spot* m);
+
+/* Upload one tensor of a reference-format state dict (host float32, contiguous, in the
+ * reference's own layout and key name, SURVEY.md §8 a-N).  Replaces
+ * model.load_state_dict(..., strict=True) (sep/helpers/utils.py:196-198).
+ * asw_spot_finalize() checks that every key arrived (strict) and packs the weights
+ * into the kernels' layouts. */
+int asw_spot_set_param(asw_spot* m, const char* key, const float* host_data, size_t numel);
+int asw_spot_finalize(asw_spot* m);
+
+/* Maximum number of candidates processed per internal batch (the reference's
+ * spot_batch_size, sep/training/JointModel/network.py:28,75). */
+int asw_spot_set_batch(asw_spot* m, int batch);
+
+/* The hot loop: replaces DataParallelSpotModel.shift_and_sep
+ * (sep/training/JointModel/network.py:37-104): for each of the N candidates,
+ * circularly advance channel m>=1 of `mix` by offsets[n][m-1] samples, int16-quantise
+ * and normalise (network.py:28-40), run the spot network with the window one-hot
+ * selected by `strict` (1 -> [1,0], else [0,1]), un-normalise (network.py:42-47).
+ *   mix      [M][T] float32 device
+ *   offsets  [N][M-1] int32 device (already rounded, JointModel/network.py:81-82)
+ *   out_wave [N][T] float32 device, or NULL
+ *   out_energy [N][2] float64 device, or NULL: (power, power2) of the mean-removed
+ *              output as computed by the stage loops (sep/helpers/local_utils_3d.py:13-17,
+ *              349-354; sep/Mic_Array.py:290-295) with window `energy_window` samples. */
+int asw_spot_shift_and_sep(asw_spot* m, const float* mix, int M, int T,
+                           const int32_t* offsets, int N, int strict, int circular,
+                           float* out_wave, double* out_energy, int energy_window,
+                           void* stream);
+
+/* Network.forward (sep/training/SpeakerLocalization/network.py:363-405) on already
+ * normalised input: mix [B][M][t], window_embedding host [2] shared by the batch ->
+ * out [B][t]. */
+int asw_spot_forward(asw_spot* m, const float* mix_norm, int B, int M, int t,
+                     const float* window_embedding_host, float* out, void* stream);
+
+/* Debug/parity tap: copy an intermediate activation of the LAST forward to `dst`
+ * (channels-last [B][T_l][C] float32).  names: "preproc", "enc0".., "bottleneck",
+ * "dec0".., "latent".  Returns the element count through *numel (dst may be NULL). */
+int asw_spot_get_tap(asw_spot* m, const char* name, float* dst, size_t capacity, size_t* numel,
+                     void* stream);
+
+/* ------------------------------------------------------------------------
+ * Individual kernels (unit-testable; the model above is built from these).
+ * ---------------------------------------------------------------------- */
+
+/* Shift + quantise + per-candidate mean / unbiased std of the mic-average
+ * (JointModel/network.py:80-83 + network.py:28-35).  mean,std: [N] float32. */
+int asw_shift_stats(const float* mix, int M, int T, const int32_t* offsets, int N,
+                    int circular, float* mean, float* std, void* stream);
+
+/* Shift + quantise + normalise + left zero-pad to T_pad + 1x1 preproc conv
+ * (network.py:36-38,377-378,385).  w [C][M], b [C];
+ * x0 [N][T_pad][C] channels-last, refn [N][refn_stride] (normalised padded mic 0; the
+ * first T_pad entries of each row are written). */
+int asw_shift_norm_preproc(const float* mix, int M, int T, int T_pad, const int32_t* offsets,
+                           int N, int circular, const float* mean, const float* std,
+                           const float* w, const float* b, int C, float* x0, float* refn,
+                           long refn_stride, void* stream);
+
+/* Normalised input variant used by asw_spot_forward: x [B][M][t] -> x0, refn. */
+int asw_pad_preproc(const float* x, int B, int M, int t, int T_pad, const float* w,
+                    const float* b, int C, float* x0, float* refn, long refn_stride,
+                    void* stream);
+
+/* 1-D convolution / transposed convolution / linear layer as an implicit GEMM on the
+ * f32 MFMA pipe with a fused epilogue.  Activations are channels-last.
+ *   out[b][r][n] = epi( sum_{tap,c} A[b][(r*stride + tap*dil - pad)*a_row_stride + c]
+ *                                    * Wt[n][tap*Cin + c] )
+ * epi: +bias[n]; ReLU (relu!=0); +resid; *mul; LayerNorm over n (ln_gamma!=NULL,
+ * requires N in {64,128,256,512,1024}); group statistics partials (stats!=NULL).
+ * Replaces nn.Conv1d / nn.ConvTranspose1d / nn.Linear + ReLU / residual / LayerNorm of
+ * network.py:57-68,105-113,190-198 and the transformer linears. */
+typedef struct asw_convgemm_args {
+  const float* A;         /* [B][a_batch_stride] */
+  const float* A2;        /* optional tensor added to A while loading (skip connection) */
+  const float* Wt;        /* [N][taps*Cin] */
+  const float* bias;      /* [N] or NULL */
+  const float* resid;     /* [B][M_out][N] or NULL */
+  const float* mul;       /* [B][M_out][N] or NULL */
+  const float* ln_gamma;  /* [N] or NULL */
+  const float* ln_beta;   /* [N] */
+  float* out;             /* [B][M_out][N] */
+  float* stats;           /* [B][tiles_m*tiles_n][4] or NULL: (sum0,sumsq0,sum1,sumsq1) */
+  int32_t B, M_out, N, Cin, taps, stride, dil, pad;
+  int32_t a_row_stride;   /* floats between consecutive input rows (normally Cin) */
+  int64_t a_batch_stride; /* floats between batch items of A */
+  int64_t a_len;          /* valid floats per batch item (bounds for zero padding) */
+  int32_t chan_mod;       /* stats: group = ((n % chan_mod) >= chan_mod/2) */
+  int32_t relu;
+  float ln_eps;
+} asw_convgemm_args;
+int asw_convgemm_f32(const asw_convgemm_args* args, void* stream);
+/* Number of stats partials per batch item the call above will write. */
+int asw_convgemm_stats_tiles(int M_out, int N);
+
+/* GroupNorm(2 groups) + GLU over channels-last raw [B][T][2C] using the partial
+ * statistics written by asw_convgemm_f32 (network.py:107-113,194-197). */
+int asw_gn_glu(const float* raw, const float* stats, int n_partials, const float* gamma,
+               const float* beta, int B, int T, int C, float eps, float* out, void* stream);
+
+/* Multi-head self-attention core: qkv [B][L][3*d] (in_proj output) -> ctx [B][L][d]
+ * (softmax(QK^T/sqrt(hd))V per head); nn.MultiheadAttention inside
+ * nn.TransformerEncoderLayer (network.py:254). */
+int asw_attention(const float* qkv, int B, int L, int d, int nhead, float* ctx, void* stream);
+
+/* output_decoder ConvTranspose1d overlap-add + trim + un-normalise
+ * (network.py:346-349,400-405; JointModel/network.py:96).
+ * D [B][F][ldd] (per-frame tap products), out [B][t]. */
+int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int taps, int hop,
+                           int T_pad, int t, int trim_left, float bias, const float* mean,
+                           const float* std, float* out, void* stream);
+
+/* Per-candidate energies: mean removal, power = sum x^2, power2 = max windowed RMS
+ * (local_utils_3d.py:13-17,349-354).  scratch: [B][T+1] float64.  out [B][2] float64. */
+int asw_energies(const float* y, int B, int T, int window, double* scratch, double* out,
+                 void* stream);
+
+/* SI-SDR of every ordered pair (est=i, ref=j) of n waveforms (eval_utils.py:11-39;
+ * call sites Mic_Array.py:353,432).  out [n][n] float64. */
+int asw_pair_sisdr(const float* y, int n, int T, double* out, void* stream);
+
+/* SRP-PHAT pruning map (sep/Traditional_SP/SRP_Prunning.py:387-434), two stages.
+ *
+ * asw_srp_cross_spectra: for each of n_windows analysis windows (start w*step, length
+ * `window`): STFT restricted to `nbins` bins (rectangular window, hop `hop`, :404-409) as
+ * a DFT-GEMM against `twiddle` [2*nb_pad][nfft] (row k: cos(2 pi (bin0+k) n / nfft),
+ * row nb_pad+k: -sin(...)), PHAT normalisation X/max(|X|,tol) (:414-416), frame-averaged
+ * cross-spectrum of the P = M(M-1)/2 pairs (pair_i < pair_j, :421-426).
+ *   mix [M][T]; xf_scratch [M][frames][2*nb_pad]; cc [n_windows][nbins][P][2] (re,im).
+ *
+ * asw_srp_map: out[g] = max(0, max_w (1/(nbins*P)) sum_{k,p} Re(cc[w][k][p] *
+ * exp(+j omega[k] (tau[g][pair_i[p]] - tau[g][pair_j[p]])))) (:428-430; the map starts
+ * from zeros, :248-256).  tau [G][M] float64 seconds (mic z ignored by the caller,
+ * :368-381); omega [nbins] float64 rad/s; part_scratch [8][8][G] float32; out [G]. */
+int asw_srp_frames(int window, int nfft, int hop);
+int asw_srp_cross_spectra(const float* mix, int M, int T, int window, int step, int n_windows,
+                          int nfft, int hop, int nbins, int nb_pad, float tol,
+                          const float* twiddle, const int32_t* pair_i, const int32_t* pair_j,
+                          int P, float* xf_scratch, float* cc, void* stream);
+int asw_srp_map(const float* cc, int n_windows, int nbins, int P, const double* tau, int G, int M,
+                const double* omega, const int32_t* pair_i, const int32_t* pair_j,
+                float* part_scratch, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASW_HIP_H */

@@ -134,6 +134,37 @@ def g2():
     _save("g2_spot_tiny", **out)
 
 
+def g2b():
+    """Spot Network.forward, SMALL config (the smallest the MFMA tiles accept), for the
+    GPU parity tests: both windows, T = 4800 and 5000."""
+    from acousticswarms_speech_amd.config import SMALL
+    net = _ref_network(SMALL, seed=21)
+    out = {}
+    for T in (4800, 5000):
+        x = _net_inputs(200 + T, 3, 7, T)
+        for wi, w in enumerate(([1.0, 0.0], [0.0, 1.0])):
+            with torch.no_grad():
+                out[f"y_T{T}_w{wi}"] = net(x, torch.tensor([w] * 3)).numpy()
+    _save("g2b_spot_small", **out)
+
+
+def g4b():
+    """DataParallelSpotModel.shift_and_sep with the FULL network (47.27 M parameters) on a
+    3-talker scene, T = 6000, 5 candidates, Strict 0/1 -- the GPU path's end-to-end pin."""
+    from sep.training.JointModel.network import DataParallelSpotModel
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.scenes import make_scene
+    net = _ref_network(FULL, seed=5)
+    model = DataParallelSpotModel(net, use_fp16=False, batch_size=4)
+    mix = torch.from_numpy(make_scene(2, 3, 7, 6000).mix)
+    offs = np.array([[0, 0, 0, 0, 0, 0], [4, -8, 12, -16, 20, -24], [-33, 45, -57, 61, -73, 87],
+                     [100, -100, 50, -50, 25, -25], [-139, 96, -72, 48, -24, 12]], dtype=np.float64)
+    patches = [_P(o) for o in offs]
+    y0 = model.shift_and_sep(mix, patches, Strict=0)
+    y1 = model.shift_and_sep(mix, patches, Strict=1)
+    _save("g4b_shift_and_sep_full", offsets=offs, y_strict0=y0, y_strict1=y1)
+
+
 def g3():
     """Spot Network.forward, FULL config (47.27 M params), T=12288, B=2; output +
     per-block activation probes captured with forward hooks."""
@@ -237,7 +268,7 @@ def main():
     install_stubs()
     torch.set_num_threads(8)
     from tests.golden import make_golden_search as mgs
-    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g9": g9}
+    todo = {"g1": g1, "g2": g2, "g2b": g2b, "g3": g3, "g4": g4, "g4b": g4b, "g5": g5, "g9": g9}
     todo.update(mgs.GENERATORS)
     sel = [s for s in args.only.split(",") if s] or list(todo)
     for k in sel:

@@ -1,0 +1,48 @@
+"""CPU-only: the C-ABI library builds/loads and exports every symbol include/asw_hip.h
+declares; the ctypes table covers exactly that set.  No compute call is made."""
+import os
+import re
+
+from acousticswarms_speech_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "asw_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return set(re.findall(r"\b(asw_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_library_exports_every_declared_symbol():
+    native.build()
+    L = native.lib()
+    syms = _declared()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in asw_hip.h but not exported"
+    assert syms == set(native.SIGNATURES), (syms ^ set(native.SIGNATURES))
+    assert L.asw_abi_version() == 1
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    """Bad arguments are rejected before any HIP call (negative status + message)."""
+    from ctypes import byref, c_void_p
+    L = native.lib()
+    cfg = native.SpotConfigC()
+    h = c_void_p()
+    assert L.asw_spot_create(byref(cfg), byref(h)) == -1          # depth 0
+    assert b"depth" in L.asw_last_error()
+    assert L.asw_convgemm_f32(None, None) == -1
+    assert L.asw_spot_shift_and_sep(None, None, 7, 100, None, 1, 0, 1, None, None, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        native.lib()
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("expected RuntimeError")

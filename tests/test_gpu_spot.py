@@ -1,0 +1,165 @@
+"""End-to-end parity of the HIP spot path (through the C ABI) against
+  (a) golden vectors produced by the reference's own code (tests/golden/*.npz), and
+  (b) the CPU oracle on the same seeded inputs.
+Tolerance (north_star): SI-SDR within 0.1 dB.  An output whose SNR against the
+reference output is S dB perturbs any SI-SDR measured with it by far less than
+0.1 dB once S >= 60 dB; the asserts below require >= 80 dB (fp32 MFMA is an exact fmaf
+chain, so only summation order differs).  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG = os.path.join(ROOT, "gpurun_out", "diag_spot.txt")
+
+
+def _log(msg):
+    os.makedirs(os.path.dirname(DIAG), exist_ok=True)
+    with open(DIAG, "a") as f:
+        f.write(msg + "\n")
+    print(msg)
+
+
+def snr_db(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return 10 * np.log10(np.sum(ref ** 2) / max(np.sum((got - ref) ** 2), 1e-300))
+
+
+def _inputs(seed, B, M, T):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.standard_normal((B, M, T)).astype(np.float32))
+
+
+def _model(cfg, seed, batch=32):
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    return SpotModel(cfg, make_spot_state_dict(cfg, seed), batch_size=batch).to("cuda")
+
+
+def test_forward_small_vs_reference_golden(golden):
+    from acousticswarms_speech_amd.config import SMALL
+    g = golden("g2b_spot_small")
+    m = _model(SMALL, 21)
+    for T in (4800, 5000):
+        x = _inputs(200 + T, 3, 7, T)
+        for wi, w in enumerate(([1.0, 0.0], [0.0, 1.0])):
+            y = m.forward(x, torch.tensor([w] * 3)).cpu().numpy()
+            ref = g[f"y_T{T}_w{wi}"]
+            s = snr_db(y, ref)
+            _log(f"small forward T={T} w={wi}: SNR vs reference {s:.1f} dB")
+            assert y.shape == ref.shape
+            assert s > 80.0
+
+
+def test_forward_small_taps_vs_oracle():
+    """Layer-by-layer: every block output against the oracle's activation."""
+    from acousticswarms_speech_amd.config import SMALL
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    from oracle import spot_ref
+    sd = make_spot_state_dict(SMALL, 21)
+    m = _model(SMALL, 21)
+    x = _inputs(5, 2, 7, 3000)
+    w = torch.tensor([[0.0, 1.0]] * 2)
+    taps = {}
+    want = spot_ref.spot_forward(sd, SMALL, x, w, taps).numpy()
+    y = m.forward(x, w).cpu().numpy()
+    for k, v in taps.items():
+        got = m.get_tap(k).cpu().numpy().reshape(v.shape[0], v.shape[2], v.shape[1])
+        s = snr_db(got, v.transpose(1, 2).numpy())
+        _log(f"small tap {k}: SNR {s:.1f} dB")
+        assert s > 90.0, k
+    assert snr_db(y, want) > 80.0
+
+
+def test_forward_mixed_window_rows():
+    """Network.forward accepts any [B,2] embedding (not only the two one-hots)."""
+    from acousticswarms_speech_amd.config import SMALL
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    from oracle import spot_ref
+    sd = make_spot_state_dict(SMALL, 21)
+    m = _model(SMALL, 21)
+    x = _inputs(6, 3, 7, 2048)
+    w = torch.tensor([[1.0, 0.0], [0.25, 0.75], [1.0, 0.0]])
+    want = spot_ref.spot_forward(sd, SMALL, x, w).numpy()
+    y = m.forward(x, w).cpu().numpy()
+    assert snr_db(y, want) > 80.0
+
+
+def test_forward_full_vs_reference_golden(golden):
+    """FULL 47.27 M-parameter network, T = 12288, B = 2 against the reference's output and
+    its per-block activation probes (fixture g3)."""
+    from acousticswarms_speech_amd.config import FULL
+    g = golden("g3_spot_full")
+    m = _model(FULL, 5)
+    x = _inputs(31, 2, 7, 12288)
+    y = m.forward(x, torch.tensor([[0.0, 1.0]] * 2)).cpu().numpy()
+    s = snr_db(y, g["y"])
+    _log(f"full forward: SNR vs reference {s:.1f} dB")
+    chans = {"preproc": 64, "bottleneck": 1024}
+    for k in ["preproc", "bottleneck"] + [f"enc{i}" for i in range(5)] + [f"dec{i}" for i in range(5)]:
+        probe, idx = g[f"{k}_probe"], g[f"{k}_idx"]            # [B, C, 16]
+        C = probe.shape[1]
+        tap = m.get_tap(k).cpu().numpy().reshape(2, -1, C)      # channels-last
+        got = tap[:, idx, :].transpose(0, 2, 1)
+        sk = snr_db(got, probe)
+        l2 = np.sqrt((tap.astype(np.float64) ** 2).sum((1, 2)))
+        _log(f"full tap {k}: probe SNR {sk:.1f} dB, l2 rel {np.abs(l2 / g[f'{k}_l2'] - 1).max():.2e}")
+        assert sk > 80.0, k
+        np.testing.assert_allclose(l2, g[f"{k}_l2"], rtol=1e-4)
+    assert s > 80.0
+
+
+def test_shift_and_sep_full_vs_reference_golden(golden):
+    """The hot loop end to end (shift -> normalise -> FULL net -> un-normalise) against the
+    reference's DataParallelSpotModel.shift_and_sep output (fixture g4b), both windows,
+    batch 2 so the ragged last batch is exercised, plus the energies fast path."""
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.scenes import make_scene
+    from oracle import spot_ref
+    g = golden("g4b_shift_and_sep_full")
+    m = _model(FULL, 5, batch=2)
+    mix = torch.from_numpy(make_scene(2, 3, 7, 6000).mix)
+
+    class P:
+        def __init__(self, o):
+            self.sample_offset = o
+    patches = [P(o) for o in g["offsets"]]
+    for strict in (0, 1):
+        y = m.shift_and_sep(mix, patches, Strict=strict)
+        ref = g[f"y_strict{strict}"]
+        assert y.shape == ref.shape and y.dtype == np.float32
+        per = [snr_db(y[i], ref[i]) for i in range(len(patches))]
+        _log(f"shift_and_sep strict={strict}: per-candidate SNR {np.round(per, 1)}")
+        assert min(per) > 80.0
+        en = m.shift_and_score(mix, patches, Strict=strict, window=1500)
+        want = spot_ref.candidate_energies(ref, 1500)
+        _log(f"energies rel err {np.abs(en / want - 1).max():.2e}")
+        np.testing.assert_allclose(en, want, rtol=1e-4)
+        assert torch.equal(m.last_waveforms.cpu(), torch.from_numpy(y))
+    assert m.shift_and_sep(mix, [], Strict=0).shape == (0, 6000)
+
+
+def test_error_behaviour():
+    from acousticswarms_speech_amd.config import SMALL, SpotConfig
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    sd = make_spot_state_dict(SMALL, 1)
+    bad = dict(sd)
+    bad.pop("preproc.bias")
+    with pytest.raises(RuntimeError):
+        SpotModel(SMALL, bad)
+    m = SpotModel(SMALL, sd)
+    with pytest.raises(RuntimeError):
+        m.shift_and_sep(torch.zeros(7, 1000), [np.zeros(6)])      # .to('cuda') not called
+    m.to("cuda")
+    with pytest.raises(RuntimeError):
+        m.shift_and_sep(torch.zeros(5, 1000), [np.zeros(4)])      # wrong mic count
+    with pytest.raises(RuntimeError):
+        m.shift_and_sep(torch.zeros(7, 1000), [np.zeros(5)])      # offsets / channels mismatch
+    with pytest.raises(RuntimeError):
+        SpotModel(SpotConfig(channels=8, encoder_channels=64, ffw_dim=32)).to("cuda")
