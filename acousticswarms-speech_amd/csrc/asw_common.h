@@ -39,3 +39,17 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace asw
+
+// ---- optional in-library launch profiler (HIP events on the launch stream) -----------
+// bench.py enables it for the timed region so per-kernel durations are measured live on
+// the stream the kernels run on; disabled (the default) it costs one branch per launch.
+#include <string>
+namespace asw {
+std::string prof_name(const char* base, int bm, int bn, int bk, bool ln, bool stats);
+struct ProfScope {
+  ProfScope(hipStream_t s, const std::string& name, double work);
+  ~ProfScope();
+  int slot;
+  hipStream_t stream;
+};
+}  // namespace asw

@@ -239,6 +239,8 @@ int launch(const asw_convgemm_args& a, hipStream_t s) {
   ASW_CHECK_ARG(a.Cin % BK == 0, "convgemm: Cin=%d not a multiple of BK=%d", a.Cin, BK);
   ASW_CHECK_ARG(a.N % BN == 0, "convgemm: N=%d not a multiple of BN=%d", a.N, BN);
   dim3 grid(asw::cdiv(a.M_out, BM), a.N / BN, a.B);
+  asw::ProfScope prof(s, asw::prof_name("convgemm", BM, BN, BK, LN, STATS),
+                      2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
   ASW_LAUNCH_CHECK();
   return ASW_OK;

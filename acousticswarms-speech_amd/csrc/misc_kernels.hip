@@ -186,13 +186,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // the last t samples (network.py:400-405), then y*std+mean (JointModel/network.py:96).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ D, int F, int ldd, int taps,
-                                                          int hop, int T_pad, int t, int trim_left, float bias,
+                                                          int hop, int t, int lead, float bias,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ stdv, float* __restrict__ out) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= t) return;
-  const int u = i + (T_pad - t) + trim_left;    // index into the untrimmed ConvTranspose output
+  const int u = i + lead;                       // index into the untrimmed ConvTranspose output
   float s = bias;
   const float* Db = D + (long)b * F * ldd;
   for (int j = u % hop; j < taps; j += hop) {
@@ -334,16 +334,19 @@ extern "C" int asw_attention(const float* qkv, int B, int L, int d, int nhead, f
   return ASW_OK;
 }
 
-extern "C" int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int taps, int hop, int T_pad, int t,
-                                      int trim_left, float bias, const float* mean, const float* std, float* out,
+extern "C" int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int taps, int hop, int t,
+                                      int trim_left, int trim_right, float bias, const float* mean, const float* std, float* out,
                                       void* stream) {
   ASW_CHECK_ARG(D && out, "overlap_add: null pointer");
-  ASW_CHECK_ARG(B > 0 && F > 0 && taps > 0 && taps <= ldd && hop > 0 && t > 0 && T_pad >= t, "overlap_add: bad shape");
+  ASW_CHECK_ARG(B > 0 && F > 0 && taps > 0 && taps <= ldd && hop > 0 && t > 0, "overlap_add: bad shape");
+  const int kept = (F - 1) * hop + taps - trim_left - trim_right;
+  ASW_CHECK_ARG(trim_left >= 0 && trim_right >= 0 && kept >= t, "overlap_add: %d samples after the trim, %d requested", kept, t);
+  const int lead = kept - t + trim_left;
   ASW_CHECK_ARG((mean == nullptr) == (std == nullptr), "overlap_add: mean/std must both be given or both NULL");
   ASW_CHECK_ARG(B <= 65535, "overlap_add: batch too large");
   dim3 grid(asw::cdiv(t, 256), B);
-  hipLaunchKernelGGL(overlap_add_kernel, grid, dim3(256), 0, asw::as_stream(stream), D, F, ldd, taps, hop, T_pad, t,
-                     trim_left, bias, mean, std, out);
+  hipLaunchKernelGGL(overlap_add_kernel, grid, dim3(256), 0, asw::as_stream(stream), D, F, ldd, taps, hop, t,
+                     lead, bias, mean, std, out);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }

@@ -415,7 +415,7 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
     a.a_row_stride = E; a.a_batch_stride = (int64_t)pl.F * E; a.a_len = a.a_batch_stride;
     if ((rc = asw_convgemm_f32(&a, s))) return rc;
   }
-  return asw_overlap_add_unnorm(pl.D, B, pl.F, 64, EK, EK / 2, pl.Tp, pl.T, 9, m->out_bias, mean, stdv, out_wave, s);
+  return asw_overlap_add_unnorm(pl.D, B, pl.F, 64, EK, EK / 2, pl.T, 9, 8, m->out_bias, mean, stdv, out_wave, s);
 }
 
 int check_ready(const asw_spot* m) {

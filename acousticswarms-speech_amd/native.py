@@ -69,6 +69,8 @@ class ConvGemmArgs(Structure):
 SIGNATURES = {
     "asw_last_error": (c_char_p, []),
     "asw_abi_version": (c_int, []),
+    "asw_profile_enable": (c_int, [c_int]),
+    "asw_profile_report": (c_int, [c_char_p, c_size_t]),
     "asw_spot_create": (c_int, [POINTER(SpotConfigC), POINTER(c_void_p)]),
     "asw_spot_destroy": (None, [c_void_p]),
     "asw_spot_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),

@@ -96,10 +96,10 @@ def shift_norm_preproc(mix, offsets, mean, std, w, b, T_pad, circular=True):
     return x0, refn
 
 
-def overlap_add_unnorm(D, taps, hop, T_pad, t, trim_left, bias, mean=None, std=None):
+def overlap_add_unnorm(D, taps, hop, t, trim_left, trim_right, bias, mean=None, std=None):
     B, F, ldd = D.shape
     out = torch.empty((B, t), dtype=torch.float32, device=D.device)
-    check(lib().asw_overlap_add_unnorm(ptr(_f32(D)), B, F, ldd, taps, hop, T_pad, t, trim_left, float(bias),
+    check(lib().asw_overlap_add_unnorm(ptr(_f32(D)), B, F, ldd, taps, hop, t, trim_left, trim_right, float(bias),
                                        ptr(mean), ptr(std), ptr(out), current_stream()))
     return out
 

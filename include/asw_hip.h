@@ -34,6 +34,13 @@ typedef enum asw_status {
 const char* asw_last_error(void);
 int asw_abi_version(void);
 
+/* Optional launch profiler: while enabled, every GEMM-class launch is bracketed by HIP
+ * events on its own stream.  asw_profile_enable(on) also clears earlier records;
+ * asw_profile_report() waits for the recorded events and writes a JSON object
+ * {"kernel<tile>": {"launches": n, "ms": total, "work": flops}, ...} into buf. */
+int asw_profile_enable(int on);
+int asw_profile_report(char* buf, size_t cap);
+
 /* ------------------------------------------------------------------------
  * Spot-network hyper-parameters.  Mirrors Network.__init__
  * (sep/training/SpeakerLocalization/network.py:268-292).
@@ -168,9 +175,11 @@ int asw_attention(const float* qkv, int B, int L, int d, int nhead, float* ctx, 
 
 /* output_decoder ConvTranspose1d overlap-add + trim + un-normalise
  * (network.py:346-349,400-405; JointModel/network.py:96).
- * D [B][F][ldd] (per-frame tap products), out [B][t]. */
+ * D [B][F][ldd] (per-frame tap products); the transposed convolution has
+ * (F-1)*hop + taps samples, of which [trim_left : -trim_right] and then the last t are
+ * kept; out [B][t]. */
 int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int taps, int hop,
-                           int T_pad, int t, int trim_left, float bias, const float* mean,
+                           int t, int trim_left, int trim_right, float bias, const float* mean,
                            const float* std, float* out, void* stream);
 
 /* Per-candidate energies: mean removal, power = sum x^2, power2 = max windowed RMS

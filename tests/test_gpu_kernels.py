@@ -210,12 +210,12 @@ def test_mask_path(ops):
     wdp = torch.zeros(64, E)
     wdp[:EK] = wd[:, 0].t()
     D, _ = ops.convgemm(Lm, wdp.cuda(), Fr, 64, E)
-    out = ops.overlap_add_unnorm(D, EK, EK // 2, Tp, t, 9, bd)
+    out = ops.overlap_add_unnorm(D, EK, EK // 2, t, 9, 8, bd)
     rel, mx = _relerr(out.cpu(), want)
     _log(f"decode rel={rel:.3e} max={mx:.3e}")
     assert rel < 3e-6
     mean, std = torch.tensor([0.1, -0.2]), torch.tensor([0.5, 2.0])
-    out2 = ops.overlap_add_unnorm(D, EK, EK // 2, Tp, t, 9, bd, mean.cuda(), std.cuda())
+    out2 = ops.overlap_add_unnorm(D, EK, EK // 2, t, 9, 8, bd, mean.cuda(), std.cuda())
     rel, _ = _relerr(out2.cpu(), want * std.view(-1, 1) + mean.view(-1, 1))
     assert rel < 3e-6
 
