@@ -112,6 +112,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+        # torch first: its bundled HIP runtime must be the one libasw_hip.so binds to, otherwise
+        # two libamdhip64 instances end up in the process and device pointers cannot be shared.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -31,7 +31,12 @@ def cpu_baseline(cfg, sd, mix, offsets, n_sample):
     """The oracle (CPU restatement of the reference, fixture-pinned) on a bounded sample of the
     same workload, on this box's host cores."""
     from oracle import spot_ref
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    # the GPU box gives one GPU a 16-core share of the host; more threads only oversubscribe
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, avail)))
     offs = [o for o in offsets[:n_sample]]
     spot_ref.shift_and_sep(sd, cfg, mix, offs[:1], strict=1)            # warm-up (thread pools, caches)
     t0 = time.perf_counter()
@@ -51,7 +56,7 @@ def main():
     ap.add_argument("--candidates", type=int, default=256, help="candidates per GPU per step")
     ap.add_argument("--samples", type=int, default=48000, help="T: 48000 = 3 s @ 16 kHz (BASELINE literal)")
     ap.add_argument("--batch", type=int, default=32, help="internal candidate batch (spot_batch_size)")
-    ap.add_argument("--cpu-sample", type=int, default=6, help="candidates timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="candidates timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-library per-kernel event timing")
     args = ap.parse_args()
 
