@@ -1,0 +1,104 @@
+"""Pipeline driver with the call surface of the reference ``JointModel``
+(sep/training/JointModel/network.py:106-215): ``setup`` / ``forward`` /
+``localize_by_separation`` / ``separate_by_localization`` and the five stage timers
+``times[0..4]`` = [SRP, coarse, fine, clustering, joint separation] seconds.
+
+Unlike the reference's timers (host ``time.time()`` with no device synchronisation,
+:143-148) each stage boundary here synchronises the device, so the numbers are true
+stage latencies.  The joint separation network (``sep_model``; speechbrain Conformer
+bottleneck) is a SURVEY.md §8f "next" row: any object with ``infer(mix, patches)`` can be
+plugged in; with ``sep_model=None`` stage 4 is skipped and ``audio`` is None.
+"""
+import time
+
+import numpy as np
+
+from .mic_array import MicArray
+
+
+def _sync():
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except ImportError:          # pragma: no cover
+        pass
+
+
+class JointModel(object):
+    def __init__(self, spot_model, sep_model=None, device=None):
+        self.spot_model = spot_model
+        self.sep_model = sep_model
+        self.device = device
+        self.times = [0, 0, 0, 0, 0]
+        self.previous_config = None
+        self.Mic_processor = None
+
+    def setup(self, mic_positions, speaker_range, cached=False, cached_folder=None):
+        """(Re)build the geometry tables unless the configuration is unchanged (:125-137).
+        One-off per geometry and excluded from latency, as the reference's README notes."""
+        key = '~'.join([f"{x:.05f}" for x in np.asarray(mic_positions).flatten()]) \
+            + '|' + '~'.join([f"{x:.05f}" for x in speaker_range])
+        if key == self.previous_config:
+            print("reuse the previous recycle!")
+            return
+        self.Mic_processor = MicArray(mic_positions, Spk_Range=speaker_range, device=self.device)
+        self.previous_config = key
+
+    def forward(self, mix_data):
+        """-> (patches, audio_loc, audio, SRP_drop, stage1_drop, spot_times) (:142-149)."""
+        self.times = [0, 0, 0, 0, 0]
+        patches, audio_loc, SRP_drop, stage1_drop, spot_times = self.localize_by_separation(mix_data)
+        _sync()
+        t0 = time.time()
+        audio = self.separate_by_localization(mix_data, patches)
+        _sync()
+        self.times[4] = time.time() - t0
+        return patches, audio_loc, audio, SRP_drop, stage1_drop, spot_times
+
+    __call__ = forward
+
+    def _timed(self, slot, fn, *args):
+        _sync()
+        t0 = time.time()
+        out = fn(*args)
+        _sync()
+        self.times[slot] = time.time() - t0
+        return out
+
+    def localize_by_separation(self, mix_data):
+        """The four search stages with the reference's empty-result early returns (:151-199)."""
+        assert self.previous_config is not None, \
+            "Microphone positions and spk range were not provided, did you forget to call .setup()?"
+        mp = self.Mic_processor
+        patch_list, _ = self._timed(0, mp.Apply_SRP_PHAT, mix_data)
+        if len(patch_list) <= 0:
+            print("No spk picked in SRP-PHAT")
+            return [], [], 0, 0, 0
+        patch_list = self._timed(1, mp.Spotform_Big_Patch, mix_data, patch_list, self.spot_model)
+        if len(patch_list) <= 0:
+            print("No spk picked in Spotform_Big_Patch")
+            return [], [], 0, 0, 0
+        output_pair = self._timed(2, mp.Spotform_Small_Patch_Parallel, mix_data, patch_list, self.spot_model)
+        if len(output_pair) <= 0:
+            print("No spk picked in Spotform_Small_Patch")
+            return [], [], 0, 0, 0
+        audio_final, patch_final, spot_times, _ = self._timed(3, mp.Clustering_new, output_pair)
+        if len(patch_final) <= 0:
+            print("No spk picked in Clustering")
+            return [], [], 0, 0, 0
+        return patch_final, np.array(audio_final), 0, 0, spot_times
+
+    def separate_by_localization(self, mix_data, target_patches):
+        if len(target_patches) == 0 or self.sep_model is None:
+            return None
+        return self.sep_model.infer(mix_data, [p[0] for p in target_patches])
+
+    def to(self, device=None):
+        if device is not None:
+            self.device = device
+            if hasattr(self.spot_model, "to"):
+                self.spot_model.to(device)
+            if self.sep_model is not None and hasattr(self.sep_model, "to"):
+                self.sep_model.to(device)
+        return self

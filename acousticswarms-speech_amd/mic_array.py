@@ -1,0 +1,217 @@
+"""Search orchestration of localization-by-separation (SURVEY.md §8 a-M): the four stage
+methods of the reference ``Mic_Array`` (sep/Mic_Array.py:95-500) with the same names,
+arguments and return layouts.  The per-candidate arithmetic (shift, spot network,
+energies) is behind ``spot_model`` on the GPU; SRP-PHAT behind ``SRPPhat``; what remains
+here is list bookkeeping, thresholds and the greedy SI-SDR clustering, which follow the
+reference including its order-dependent quirks (documented inline).
+"""
+import numpy as np
+
+from . import search
+from .hostdsp import max_avg_power, si_sdr, split_wav, split_wise_sisdr
+from .patch import FS, SPEED_OF_SOUND, Patch
+from .search import (INIT_WIDTH, SPOT_POWER_THRESHOLD2, USE_RELATIVE_SPOT_POWER, binary_search_baseline,
+                     search_area)
+from .srp import SRPPhat
+
+# sep/helpers/constants.py:24-27
+BIN0, BIN1, N_FFT = 2, 200, 2048
+FREQ_BINS = np.arange(BIN0, BIN1)
+
+
+def check_sisnr_win(sisnr_list, SISNR_THRESHOLD=-2, SISNR_THRESHOLD2=-7):
+    """Same talker if some segment is similar (> thr) and none is very different (< thr2)
+    (sep/Mic_Array.py:18-28)."""
+    v = np.asarray(list(sisnr_list), dtype=np.float64)
+    return bool(np.any(v > SISNR_THRESHOLD) and not np.any(v < SISNR_THRESHOLD2))
+
+
+def weight_mean_pos(patch_list, powers, id_lists):
+    """Power-weighted mean position / offsets over the cluster members within 75 % of the
+    head's power (sep/Mic_Array.py:32-47)."""
+    head = powers[id_lists[0]]
+    pos = np.zeros((3,))
+    offs = np.zeros(patch_list[0].sample_offset.shape)
+    tot = 0
+    for i in id_lists:
+        if powers[i] < head * 0.75:
+            continue
+        pos += powers[i] * patch_list[i].center_pos()
+        offs += powers[i] * patch_list[i].sample_offset
+        tot += powers[i]
+    return pos / tot, offs / tot
+
+
+def find_merge_center(merged_offests, init_area, mic_positions, Big_patch_center):
+    """Patch of width 3 around the merged offsets holding the coarse patch's points that fall
+    inside; falls back to the coarse centre (sep/Mic_Array.py:50-81).  The reference's
+    widening loop leaves after its first pass (factor 0), which repeats the width-3 test."""
+    P = mic_positions.shape[0] - 1
+    patch = Patch(merged_offests, [3 for _ in range(P)], None)
+    inside = patch.hyperbola_general_area(init_area[0, :], init_area[1, :], init_area[2, :], mic_positions,
+                                          SPEED_OF_SOUND, FS) == 1
+    if np.sum(inside) == 0:
+        patch.width_list = [3 for _ in range(P)]
+        inside = patch.hyperbola_general_area(init_area[0, :], init_area[1, :], init_area[2, :], mic_positions,
+                                              SPEED_OF_SOUND, FS) == 1
+        if np.sum(inside) > 0:
+            patch.area_points = init_area[:, inside]
+        else:
+            patch.peak_pos = Big_patch_center
+    else:
+        patch.area_points = init_area[:, inside]
+    return patch
+
+
+class MicArray(object):
+    def __init__(self, mic_positions, demo=False, Spk_Range=None, grid_size=0.05, Prone_method="SRP",
+                 MIN_TRIGGER_POWER=0.5, SRP_fast=False, cached=False, cached_folder=None, device=None):
+        if Prone_method != "SRP":
+            raise RuntimeError("only the SRP-PHAT pruner is provided (MUSIC/TOPS are out of scope)")
+        self.Prone_method = Prone_method
+        self.MIN_TRIGGER_POWER = MIN_TRIGGER_POWER
+        self.visual_save = False
+        self.Range_spk = Spk_Range
+        print("Init the Range_spk: ", Spk_Range)
+        self.mic_positions = mic_positions
+        self.num_mic = mic_positions.shape[0]
+        # physical TDoA bound per pair, 8 cm slack (sep/Mic_Array.py:114-116)
+        self.upper_bound_pairwise = (np.linalg.norm(mic_positions[1:] - mic_positions[0], axis=1) + 0.08) \
+            / SPEED_OF_SOUND * FS
+        self.SRP_node = SRPPhat(mic_pos=mic_positions, freq_bins=FREQ_BINS, Range_spk=Spk_Range, grid_size=grid_size,
+                                FS=FS, n_fft=N_FFT, threshold=[0.15, 0.015, 0.05], WIDTH=INIT_WIDTH, device=device)
+        self.original_times = 0
+        self.spotforming_times = 0
+        self.big_spotforming_times = 0
+
+    # ---- stage 1: SRP-PHAT pruning (sep/Mic_Array.py:152-194) ---------------------------
+    def Apply_SRP_PHAT(self, mix_data):
+        self.SRP_node.reset()
+        self.spotforming_times = 0
+        self.original_times = 0
+        mix_np = mix_data.numpy() if hasattr(mix_data, "numpy") else np.asarray(mix_data)
+        win = 36000 if mix_np.shape[1] >= 72000 else 24000
+        self.SRP_node.SRP_Map_WINDOW_new(mix_np, window=win)
+        patch_list = self.SRP_node.local_source_adaptive()
+        return patch_list, np.zeros((3, 3))
+
+    # ---- stage 2: coarse Spotforming, relaxed window (sep/Mic_Array.py:196-222) ---------
+    def Spotform_Big_Patch(self, mix_data, patch_list, spot_model):
+        self.big_spotforming_times = len(patch_list)
+        kept, _powers_with_dis, rel_thr = binary_search_baseline(mix_data, spot_model, patch_list,
+                                                                 self.mic_positions)
+        self.Relative_Threshold = rel_thr
+        return kept
+
+    # ---- stage 3: fine Spotforming, strict window (sep/Mic_Array.py:225-395) ------------
+    def Spotform_Small_Patch_Parallel(self, mix_data, candidate_finished, spot_model, sample_gt=None,
+                                      run_demo_folder=None):
+        P = self.num_mic - 1
+        thr_new = min([SPOT_POWER_THRESHOLD2, self.Relative_Threshold]) if USE_RELATIVE_SPOT_POWER \
+            else SPOT_POWER_THRESHOLD2
+        total_patch, bounds, areas, centers = [], [0], [], []
+        self.spotforming_times = 0
+        for big in candidate_finished:
+            fine = search_area([big], self.mic_positions, self.upper_bound_pairwise)
+            areas.append(big.area_points)
+            centre_patch = Patch(big.sample_offset, [2 for _ in range(P)], None, big.peak_pos)
+            c = centre_patch.center_pos()
+            centers.append(c)
+            if c is not None:
+                fine.append(centre_patch)                 # the centre candidate goes last (:256-257)
+            else:
+                print("it is impossible to be here")
+            self.spotforming_times += len(fine)
+            total_patch.extend(fine)
+            bounds.append(self.spotforming_times)
+
+        sep_all = spot_model.shift_and_sep(mix_data, total_patch, Strict=1)      # the hot call
+
+        output_pair = []
+        for i in range(len(bounds) - 1):
+            big = candidate_finished[i]
+            big_label = -1
+            if sample_gt is not None:
+                for k in range(sample_gt.shape[1]):
+                    if np.amax(np.abs(big.sample_offset - sample_gt[:, k])) < 3.5:
+                        big_label = k
+                        break
+            sep = sep_all[bounds[i]:bounds[i + 1]]
+            patches = total_patch[bounds[i]:bounds[i + 1]]
+            powers, powers2 = [], []
+            for j in range(len(patches)):
+                sep[j, :] = sep[j, :] - np.mean(sep[j, :])                 # in place, as :291
+                powers.append(np.sum(sep[j, :] ** 2))
+                powers2.append(max_avg_power(sep[j, :]))
+            c = big.center_pos()
+            d = np.linalg.norm(c - self.mic_positions[0]) if c.shape[0] == 3 else 4
+            if np.amax(powers2) < thr_new / (1 + d):
+                continue
+            order = np.argsort(-1 * np.array(powers))                       # sorted by total power (:339)
+            clusters = {}
+            # the reference scales the trigger by the length of the LAST candidate row (:343)
+            min_trigger = self.MIN_TRIGGER_POWER / (3 * 48000) * sep[len(patches) - 1, :].shape[0]
+            for k in order:
+                d = np.linalg.norm(patches[k].center_pos() - self.mic_positions[0])
+                if powers2[k] < thr_new / (1 + d) or powers[k] < min_trigger:
+                    continue
+                home = None
+                for head in clusters:
+                    if si_sdr(sep[k, :], sep[clusters[head][0]]) > -4:      # SI_SDR_THRESHOLD (:340)
+                        home = head
+                        break
+                if home is None:
+                    clusters[k] = [k]
+                else:
+                    clusters[home].append(k)
+            if len(clusters) == 0:
+                continue
+            for head in clusters:
+                _position, offs = weight_mean_pos(patches, powers, clusters[head])
+                centre = find_merge_center(offs, areas[i], self.mic_positions, centers[i])
+                if centre.center_pos() is None:
+                    print("Warning some bug happen one source may be drop")
+                output_pair.append((centre, sep[head, :], powers[head], str(i) + '_' + str(head),
+                                    {"audio_offset": patches[head].sample_offset, "localization_offset": offs},
+                                    big_label))
+        return output_pair
+
+    # ---- stage 4: global non-max suppression (sep/Mic_Array.py:399-500) -----------------
+    def Clustering_new(self, output_pair, simple_pos=None, sample_gt=None):
+        cands = sorted(output_pair, key=lambda x: -x[2])
+        clusters = {}
+        wrong = []
+        for i, cand in enumerate(cands):
+            centre1, audio1, power1, big_label = cand[0].center_pos(), cand[1], cand[2], cand[-1]
+            segs = split_wav(audio1)
+            if len(segs) == 0:
+                print("discard because no invalid split!!!")
+                continue
+            unique, belong = True, -1
+            seg_tab = []
+            for head in clusters:
+                h = clusters[head][0]
+                audio2, centre2 = cands[h][1], cands[h][0].center_pos()
+                sim = si_sdr(audio1, audio2)
+                per_seg = split_wise_sisdr(audio1, audio2, segs)
+                seg_tab.append(per_seg)
+                dis = np.linalg.norm(centre1[:2] - centre2[:2])
+                if sim > -1 or check_sisnr_win(per_seg) or dis < 0.45:      # (:401,458)
+                    clusters[h].append(i)
+                    unique, belong = False, head
+                    break
+            if len(seg_tab) != 0:
+                best = np.amax(np.array(seg_tab), axis=0)
+                if check_sisnr_win(best, SISNR_THRESHOLD=-1, SISNR_THRESHOLD2=-5):
+                    unique = False
+            if unique:
+                clusters[i] = [i]
+            elif big_label >= 0 and sample_gt is not None and belong >= 0:
+                h = clusters[belong][0]
+                if cands[h][-1] == -1:
+                    delta = (cands[h][-2]["audio_offset"] - sample_gt[:, big_label]).astype(int)
+                    wrong.append((big_label, cands[h][-1], delta, power1 / cands[h][2]))
+        print("final speaker number is ", len(clusters.keys()))
+        patch_final = [cands[clusters[h][0]] for h in clusters]
+        audio_final = [p[1] for p in patch_final]
+        return audio_final, patch_final, self.big_spotforming_times + self.spotforming_times, wrong

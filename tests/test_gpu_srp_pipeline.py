@@ -1,0 +1,89 @@
+"""GPU: SRP-PHAT map kernels against the reference's map (fixture g7) and the whole
+search pipeline (device SRP map -> coarse -> fine -> clustering) against the reference's
+stage trace (fixture g10, surrogate scorer).  Needs an MI355X."""
+import io
+import os
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.make_golden_search import ROI, scene_in_roi
+from tests.golden.surrogate import SurrogateSpot
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _log(msg):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "diag_srp.txt"), "a") as f:
+        f.write(msg + "\n")
+    print(msg)
+
+
+@pytest.fixture(scope="module")
+def mic_array():
+    from acousticswarms_speech_amd.mic_array import MicArray
+    mics, spk, mix = scene_in_roi()
+    with redirect_stdout(io.StringIO()):
+        ma = MicArray(mics, Spk_Range=ROI, device="cuda")
+    return ma, mics, spk, mix
+
+
+def test_srp_map_matches_reference(mic_array, golden):
+    ma, _, _, mix = mic_array
+    g7 = golden("g7_srp_map")
+    node = ma.SRP_node
+    node.reset()
+    node.SRP_Map_WINDOW_new(mix, window=24000)
+    got, ref = node.SRP_map.astype(np.float64), g7["srp_map"]
+    err = np.abs(got - ref).max()
+    _log(f"SRP map: max abs err {err:.3e} (map max {ref.max():.4f}), rel l2 {np.linalg.norm(got-ref)/np.linalg.norm(ref):.3e}")
+    # fp32 DFT-GEMM + fp32 sincos against the reference's complex64 x float64 table
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5)
+    assert abs(node.MAX_POWER - float(g7["max_power"])) < 1e-4
+    # odd length (not a multiple of 4) goes through the padded path
+    node.SRP_Map_WINDOW_new(mix[:, :47999], window=24000)
+    from oracle import srp_ref
+    from acousticswarms_speech_amd.mic_array import FREQ_BINS, N_FFT
+    want = srp_ref.srp_map(mix[:, :47999], 24000, N_FFT, FREQ_BINS, node.tau, node.omega)
+    np.testing.assert_allclose(node.SRP_map, want, rtol=2e-4, atol=2e-5)
+
+
+def test_pipeline_trace_with_device_srp(mic_array, golden):
+    """JointModel.forward end to end: SRP map from the HIP kernels, surrogate scorer."""
+    from acousticswarms_speech_amd.joint import JointModel
+    ma, mics, spk, mix = mic_array
+    g = golden("g10_stage_trace")
+    spot = SurrogateSpot()
+    jm = JointModel(spot, None, device="cuda")
+    with redirect_stdout(io.StringIO()):
+        jm.setup(mics, ROI)
+        patches, audio_loc, audio, _, _, spot_times = jm.forward(torch.from_numpy(mix))
+    _log(f"pipeline: calls {spot.calls}, final {[p[3] for p in patches]}, times {np.round(jm.times, 3)}")
+    assert audio is None and audio_loc.shape == (len(patches), mix.shape[1])
+    assert spot.calls == [tuple(c) for c in g["calls"].tolist()]
+    assert [p[3] for p in patches] == g["final_names"].tolist()
+    np.testing.assert_allclose(np.stack([p[0].center_pos() for p in patches]), g["final_center"], atol=1e-6)
+    assert spot_times == int(g["spot_times"])
+    assert all(t >= 0 for t in jm.times) and jm.times[0] > 0
+
+
+def test_pipeline_with_hip_spot_model(mic_array):
+    """Same pipeline with the real HIP spot model (seeded random weights): exercises the
+    product path of every stage; a random network finds no talkers, so the reference's
+    empty-result convention must come back."""
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.joint import JointModel
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    ma, mics, spk, mix = mic_array
+    spot = SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=32).to("cuda")
+    jm = JointModel(spot, None, device="cuda")
+    with redirect_stdout(io.StringIO()):
+        jm.setup(mics, ROI)
+        out = jm.forward(torch.from_numpy(mix[:, :24000 * 2]))
+    _log(f"pipeline(HIP spot, random weights): n_final={len(out[0])} times={np.round(jm.times, 3)}")
+    assert len(out) == 6
