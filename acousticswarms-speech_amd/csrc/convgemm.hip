@@ -1,6 +1,5 @@
 // convgemm.hip -- 1-D conv / transposed conv / linear as implicit GEMM on the gfx950
-// f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain), with the layer's
-// element-wise tail fused into the epilogue.
+// matrix cores, with the layer's element-wise tail fused into the epilogue.
 //
 // Replaces (reference file:line): DilatedResidualLayer conv+ReLU+residual+LayerNorm
 // (sep/training/SpeakerLocalization/network.py:57-68), EncoderBlock.conv1
@@ -11,15 +10,23 @@
 // Layout: activations channels-last [B][T][C] fp32, weights Wt[N][K] with
 // K = tap*Cin + c.  One workgroup (256 threads = 4 waves) owns a BM x BN output tile
 // of one batch item; K is walked in chunks of BK channels of one tap.  A and W chunks
-// are staged global -> registers -> LDS (row stride BK+4 floats: the ds_read_b128
-// fragment reads below are then bank-conflict free), the next chunk's global loads
-// are in flight while the MFMAs of the current chunk run.
+// are staged global -> registers -> LDS, the next chunk's global loads are in flight
+// while the MFMAs of the current chunk run.
 //
-// MFMA operand order: for v_mfma_f32_32x32x2_f32 lane l supplies A[i=l&31][k=l>>5] and
-// B[k=l>>5][j=l&31].  A lane reads 4 consecutive k (one b128) at column
-// kk*8 + 4*(l>>5) of its row; step s of 4 uses element s of both operands, so the
-// logical k visited by (step s, half h) is kk*8 + 4h + s for A and B alike -- any
-// consistent permutation of k is a valid GEMM.
+// Two arithmetic modes share the tiling and the epilogue:
+//  * precision 0: v_mfma_f32_32x32x2_f32 -- an exact fp32 fmaf chain (64 FLOP/clk/SIMD).
+//    Lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; a lane reads 4 consecutive
+//    k (one ds_read_b128) and step s of 4 uses element s of both operands, i.e. the k
+//    order is permuted identically for A and B.  LDS rows are padded to BK+4 floats so
+//    those reads are bank-conflict free.
+//  * precision 1 ("f16x3"): every fp32 operand is split into two halves hi = fp16(x),
+//    lo = fp16(x - hi) and the product is lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16
+//    with fp32 accumulation: operands carry ~21 bits, the dropped lo*lo term is 2^-22 of the
+//    product, and the pipe runs 16/3 = 5.3x the f32 MFMA rate.  Activations are split while
+//    they are staged to LDS (saturating at +-65504); weights are split once on the host,
+//    pre-scaled by a power of two (undone in the epilogue) so their lo parts stay out of the
+//    fp16 subnormal range.  Lane l supplies A[l&31][8(l>>5)+j], j<8: one ds_read_b128 per
+//    operand half per k-step; rows padded to BK+8 halves (conflict free).
 //
 // Epilogue: the accumulators of one 32-row slab are written to LDS (C/D map:
 // col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)), then each wave owns whole
@@ -30,6 +37,8 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -37,6 +46,105 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ------------------------------------------------------------------ shared epilogue
+template <int BM, int BN, int WM, int WN, bool LN, bool STATS>
+__device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
+                                         float* smem, float acc_scale) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int LDC = BN + 4;
+  constexpr int NQ = BN / 64;
+  float* Ct = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  float st0 = 0.f, sq0 = 0.f, st1 = 0.f, sq1 = 0.f;
+  const int half_mod = p.chan_mod >> 1;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = wn * (BN / WN) + tn * 32 + (lane & 31);
+      const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[tm][tn][r] * acc_scale + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        Ct[row * LDC + col] = v;
+      }
+    }
+    __syncthreads();
+    for (int sr = wid; sr < WM * 32; sr += 4) {
+      const int trow = (sr >> 5) * (BM / WM) + tm * 32 + (sr & 31);
+      const int t_out = m0 + trow;
+      if (t_out >= p.M_out) continue;           // wave-uniform
+      const long obase = ((long)b * p.M_out + t_out) * p.N + n0;
+      float v[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int col = lane + 64 * q;
+        float x = Ct[sr * LDC + col];
+        if (p.resid) x += p.resid[obase + col];
+        if (p.mul) x *= p.mul[obase + col];
+        v[q] = x;
+      }
+      if (LN) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s += v[q];
+        const float mean = wave_sum(s) * (1.0f / BN);
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { const float c = v[q] - mean; d += c * c; }
+        const float var = wave_sum(d) * (1.0f / BN);
+        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int col = lane + 64 * q;
+          v[q] = (v[q] - mean) * rstd * p.ln_gamma[col] + p.ln_beta[col];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int col = lane + 64 * q;
+        if (STATS) {
+          const bool g1 = ((n0 + col) % p.chan_mod) >= half_mod;
+          const float x = v[q];
+          if (g1) { st1 += x; sq1 += x * x; } else { st0 += x; sq0 += x * x; }
+        }
+        p.out[obase + col] = v[q];
+      }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    st0 = wave_sum(st0); sq0 = wave_sum(sq0); st1 = wave_sum(st1); sq1 = wave_sum(sq1);
+    float* red = smem;                           // Ct is dead after the barrier above
+    if (lane == 0) { red[wid * 4 + 0] = st0; red[wid * 4 + 1] = sq0; red[wid * 4 + 2] = st1; red[wid * 4 + 3] = sq1; }
+    __syncthreads();
+    if (tid < 4) {
+      const float s = red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
+      const long part = ((long)b * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y;
+      p.stats[part * 4 + tid] = s;
+    }
+  }
+}
+
+// address of the float4 of A this thread stages for chunk kc (or -1 when it is padding)
+template <int BM, int BK>
+__device__ __forceinline__ long a_elem(const asw_convgemm_args& p, int idx, int kc, int cpb, int m0) {
+  constexpr int KV = BK / 4;
+  const int tap = kc / cpb;
+  const int c0 = (kc - tap * cpb) * BK;
+  const int row = idx / KV, cv = idx - row * KV;
+  const int t_out = m0 + row;
+  const long e = ((long)t_out * p.stride + (long)tap * p.dil - p.pad) * p.a_row_stride + c0 + cv * 4;
+  const bool ok = (idx < BM * KV) && (t_out < p.M_out) && (e >= 0) && (e + 3 < p.a_len);
+  return ok ? e : -1;
+}
+
+// ------------------------------------------------------------------ exact fp32 MFMA
 template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS>
 __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -44,13 +152,10 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p
   constexpr int KV = BK / 4;                 // float4 per staged row
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_VEC = (BM * KV + 255) / 256, B_VEC = (BN * KV + 255) / 256;
-  constexpr int LDC = BN + 4;
-  constexpr int NQ = BN / 64;
 
   extern __shared__ __align__(16) float smem[];
   float* As = smem;
   float* Bs = smem + BM * LDK;
-  float* Ct = smem;                          // epilogue slab, reuses the staging area
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
@@ -64,17 +169,11 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p
   float4 ra[A_VEC], rb[B_VEC];
 
   auto gload = [&](int kc) {
-    const int tap = kc / cpb;
-    const int c0 = (kc - tap * cpb) * BK;
 #pragma unroll
     for (int v = 0; v < A_VEC; ++v) {
-      const int idx = tid + v * 256;
-      const int row = idx / KV, cv = idx - row * KV;
-      const int t_out = m0 + row;
-      const long e = ((long)t_out * p.stride + (long)tap * p.dil - p.pad) * p.a_row_stride + c0 + cv * 4;
-      const bool ok = (idx < BM * KV) && (t_out < p.M_out) && (e >= 0) && (e + 3 < p.a_len);
+      const long e = a_elem<BM, BK>(p, tid + v * 256, kc, cpb, m0);
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
+      if (e >= 0) {
         x = *reinterpret_cast<const float4*>(Ab + e);
         if (A2b) {
           const float4 y = *reinterpret_cast<const float4*>(A2b + e);
@@ -146,104 +245,178 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p
       }
     }
   }
+  epilogue<BM, BN, WM, WN, LN, STATS>(acc, p, smem, 1.0f);
+}
 
-  // ------------------------------------------------------------------ epilogue
-  float st0 = 0.f, sq0 = 0.f, st1 = 0.f, sq1 = 0.f;
-  const int half_mod = p.chan_mod >> 1;
+// ------------------------------------------------------------------ f16x3 split MFMA
+__device__ __forceinline__ void split4(const float4 x, half4& hi, half4& lo) {
+  const float v[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    __syncthreads();
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = wn * (BN / WN) + tn * 32 + (lane & 31);
-      const float bv = p.bias ? p.bias[n0 + col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = acc[tm][tn][r] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        Ct[row * LDC + col] = v;
-      }
-    }
-    __syncthreads();
-    for (int sr = wid; sr < WM * 32; sr += 4) {
-      const int trow = (sr >> 5) * (BM / WM) + tm * 32 + (sr & 31);
-      const int t_out = m0 + trow;
-      if (t_out >= p.M_out) continue;           // wave-uniform
-      const long obase = ((long)b * p.M_out + t_out) * p.N + n0;
-      float v[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int col = lane + 64 * q;
-        float x = Ct[sr * LDC + col];
-        if (p.resid) x += p.resid[obase + col];
-        if (p.mul) x *= p.mul[obase + col];
-        v[q] = x;
-      }
-      if (LN) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) s += v[q];
-        const float mean = wave_sum(s) * (1.0f / BN);
-        float d = 0.f;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { const float c = v[q] - mean; d += c * c; }
-        const float var = wave_sum(d) * (1.0f / BN);
-        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int col = lane + 64 * q;
-          v[q] = (v[q] - mean) * rstd * p.ln_gamma[col] + p.ln_beta[col];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int col = lane + 64 * q;
-        if (STATS) {
-          const bool g1 = ((n0 + col) % p.chan_mod) >= half_mod;
-          const float x = v[q];
-          if (g1) { st1 += x; sq1 += x * x; } else { st0 += x; sq0 += x * x; }
-        }
-        p.out[obase + col] = v[q];
-      }
-    }
-  }
-  if (STATS) {
-    __syncthreads();
-    st0 = wave_sum(st0); sq0 = wave_sum(sq0); st1 = wave_sum(st1); sq1 = wave_sum(sq1);
-    float* red = smem;                           // Ct is dead after the barrier above
-    if (lane == 0) { red[wid * 4 + 0] = st0; red[wid * 4 + 1] = sq0; red[wid * 4 + 2] = st1; red[wid * 4 + 3] = sq1; }
-    __syncthreads();
-    if (tid < 4) {
-      const float s = red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
-      const long part = ((long)b * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y;
-      p.stats[part * 4 + tid] = s;
-    }
+  for (int i = 0; i < 4; ++i) {
+    const float c = fminf(fmaxf(v[i], -65504.f), 65504.f);
+    const _Float16 h = (_Float16)c;
+    hi[i] = h;
+    lo[i] = (_Float16)(c - (float)h);
   }
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS>
+__global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BK % 16 == 0, "k-step of the f16 MFMA");
+  constexpr int LDH = BK + 8;                // halves per staged row
+  constexpr int KV = BK / 4;                 // float4 (A, fp32) per row
+  constexpr int KH = BK / 8;                 // 16-byte vectors (B, fp16) per row
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_VEC = (BM * KV + 255) / 256, B_VEC = (BN * KH + 255) / 256;
+
+  extern __shared__ __align__(16) float smem[];
+  _Float16* Ah = reinterpret_cast<_Float16*>(smem);
+  _Float16* Al = Ah + BM * LDH;
+  _Float16* Bh = Al + BM * LDH;
+  _Float16* Bl = Bh + BN * LDH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int K = p.taps * p.Cin;
+  const int cpb = p.Cin / BK;
+  const int nk = p.taps * cpb;
+  const float* __restrict__ Ab = p.A + (long)b * p.a_batch_stride;
+  const float* __restrict__ A2b = p.A2 ? p.A2 + (long)b * p.a_batch_stride : nullptr;
+  const _Float16* __restrict__ Wh = reinterpret_cast<const _Float16*>(p.Wt_hi);
+  const _Float16* __restrict__ Wl = reinterpret_cast<const _Float16*>(p.Wt_lo);
+
+  float4 ra[A_VEC];
+  half8 rbh[B_VEC], rbl[B_VEC];
+
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int v = 0; v < A_VEC; ++v) {
+      const long e = a_elem<BM, BK>(p, tid + v * 256, kc, cpb, m0);
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e >= 0) {
+        x = *reinterpret_cast<const float4*>(Ab + e);
+        if (A2b) {
+          const float4 y = *reinterpret_cast<const float4*>(A2b + e);
+          x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        }
+      }
+      ra[v] = x;
+    }
+#pragma unroll
+    for (int v = 0; v < B_VEC; ++v) {
+      const int idx = tid + v * 256;
+      const int row = idx / KH, cv = idx - row * KH;
+      half8 h, l;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { h[i] = (_Float16)0.f; l[i] = (_Float16)0.f; }
+      if (idx < BN * KH && n0 + row < p.N) {
+        const long o = (long)(n0 + row) * K + (long)kc * BK + cv * 8;
+        h = *reinterpret_cast<const half8*>(Wh + o);
+        l = *reinterpret_cast<const half8*>(Wl + o);
+      }
+      rbh[v] = h;
+      rbl[v] = l;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int v = 0; v < A_VEC; ++v) {
+      const int idx = tid + v * 256;
+      const int row = idx / KV, cv = idx - row * KV;
+      if (idx < BM * KV) {
+        half4 hi, lo;
+        split4(ra[v], hi, lo);
+        *reinterpret_cast<half4*>(Ah + row * LDH + cv * 4) = hi;
+        *reinterpret_cast<half4*>(Al + row * LDH + cv * 4) = lo;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < B_VEC; ++v) {
+      const int idx = tid + v * 256;
+      const int row = idx / KH, cv = idx - row * KH;
+      if (idx < BN * KH) {
+        *reinterpret_cast<half8*>(Bh + row * LDH + cv * 8) = rbh[v];
+        *reinterpret_cast<half8*>(Bl + row * LDH + cv * 8) = rbl[v];
+      }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int a_off = (wm * (BM / WM) + (lane & 31)) * LDH + (lane >> 5) * 8;
+  const int b_off = (wn * (BN / WN) + (lane & 31)) * LDH + (lane >> 5) * 8;
+
+  gload(0);
+  for (int kc = 0; kc < nk; ++kc) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (kc + 1 < nk) gload(kc + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(Ah + a_off + i * 32 * LDH + ks * 16);
+        al[i] = *reinterpret_cast<const half8*>(Al + a_off + i * 32 * LDH + ks * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const half8*>(Bh + b_off + j * 32 * LDH + ks * 16);
+        bl[j] = *reinterpret_cast<const half8*>(Bl + b_off + j * 32 * LDH + ks * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  epilogue<BM, BN, WM, WN, LN, STATS>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift));
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool F16>
 int launch(const asw_convgemm_args& a, hipStream_t s) {
-  constexpr int LDK = BK + 4;
-  constexpr size_t stage = (size_t)(BM + BN) * LDK * sizeof(float);
+  constexpr size_t stage = F16 ? (size_t)(BM + BN) * (BK + 8) * 2 * sizeof(_Float16)
+                               : (size_t)(BM + BN) * (BK + 4) * sizeof(float);
   constexpr size_t slab = (size_t)(WM * 32) * (BN + 4) * sizeof(float);
   constexpr size_t smem = stage > slab ? stage : slab;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  auto kern = convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS>;
+  const void* kern = F16 ? reinterpret_cast<const void*>(convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS>)
+                         : reinterpret_cast<const void*>(convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS>);
   static bool attr_set = false;
   if (!attr_set) {
-    ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    ASW_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
   ASW_CHECK_ARG(a.Cin % BK == 0, "convgemm: Cin=%d not a multiple of BK=%d", a.Cin, BK);
   ASW_CHECK_ARG(a.N % BN == 0, "convgemm: N=%d not a multiple of BN=%d", a.N, BN);
   dim3 grid(asw::cdiv(a.M_out, BM), a.N / BN, a.B);
-  asw::ProfScope prof(s, asw::prof_name("convgemm", BM, BN, BK, LN, STATS),
+  asw::ProfScope prof(s, asw::prof_name(F16 ? "convgemm16" : "convgemm", BM, BN, BK, LN, STATS),
                       2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  if (F16)
+    hipLaunchKernelGGL((convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS>), grid, dim3(256), smem, s, a);
+  else
+    hipLaunchKernelGGL((convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS>), grid, dim3(256), smem, s, a);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS>
+int launch_prec(const asw_convgemm_args& a, hipStream_t s) {
+  return a.precision == 1 ? launch<BM, BN, BK, WM, WN, LN, STATS, true>(a, s)
+                          : launch<BM, BN, BK, WM, WN, LN, STATS, false>(a, s);
 }
 
 // tile choice for the non-LayerNorm variants; must match asw_convgemm_stats_tiles
@@ -256,14 +429,46 @@ extern "C" int asw_convgemm_stats_tiles(int M_out, int N) {
   return asw::cdiv(M_out, 256) * (N / 64);
 }
 
+extern "C" int asw_split_weights_f16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, int32_t* w_shift) {
+  ASW_CHECK_ARG(w && hi && lo && w_shift, "split_weights: null pointer");
+  float mx = 0.f;
+  for (size_t i = 0; i < n; ++i) { const float a = w[i] < 0 ? -w[i] : w[i]; if (a > mx) mx = a; }
+  ASW_CHECK_ARG(mx == mx && mx < 3.0e38f, "split_weights: non-finite weight");
+  // largest power of two with max|w| * 2^shift < 2048 (fp16 keeps 11 significant bits there and
+  // typical weights, 10-100x below the maximum, still have normal lo parts); bounded to +-24.
+  int shift = 0;
+  if (mx > 0.f) {
+    int e;
+    (void)frexpf(mx, &e);                  // mx = f * 2^e, f in [0.5,1)
+    shift = 11 - e;
+    if (shift > 24) shift = 24;
+    if (shift < -24) shift = -24;
+  }
+  const float sc = ldexpf(1.0f, shift);
+  for (size_t i = 0; i < n; ++i) {
+    float c = w[i] * sc;
+    if (c > 65504.f) c = 65504.f;
+    if (c < -65504.f) c = -65504.f;
+    const _Float16 h = (_Float16)c;
+    const _Float16 l = (_Float16)(c - (float)h);
+    memcpy(hi + i, &h, 2);
+    memcpy(lo + i, &l, 2);
+  }
+  *w_shift = shift;
+  return ASW_OK;
+}
+
 extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
   ASW_CHECK_ARG(args != nullptr, "convgemm: null args");
   const asw_convgemm_args& a = *args;
   hipStream_t s = asw::as_stream(stream);
-  ASW_CHECK_ARG(a.A && a.Wt && a.out, "convgemm: null tensor");
+  ASW_CHECK_ARG(a.A && a.out, "convgemm: null tensor");
+  ASW_CHECK_ARG(a.precision == 0 || a.precision == 1, "convgemm: precision %d", a.precision);
+  if (a.precision == 1) ASW_CHECK_ARG(a.Wt_hi && a.Wt_lo, "convgemm: f16x3 needs Wt_hi/Wt_lo");
+  else ASW_CHECK_ARG(a.Wt != nullptr, "convgemm: null weights");
   ASW_CHECK_ARG(a.B > 0 && a.M_out > 0 && a.N > 0 && a.Cin > 0 && a.taps > 0, "convgemm: bad dims");
-  ASW_CHECK_ARG(a.a_row_stride % 4 == 0 && a.a_batch_stride % 4 == 0 && a.a_len % 4 == 0 && a.Cin % 4 == 0,
-                "convgemm: strides must be multiples of 4 floats");
+  ASW_CHECK_ARG(a.a_row_stride % 4 == 0 && a.a_batch_stride % 4 == 0 && a.a_len % 4 == 0 && a.Cin % 8 == 0,
+                "convgemm: strides must be multiples of 4 floats, Cin of 8");
   ASW_CHECK_ARG(a.B <= 65535, "convgemm: batch %d exceeds grid.z", a.B);
   const bool stats = a.stats != nullptr;
   if (stats) ASW_CHECK_ARG(a.chan_mod >= 2 && a.chan_mod % 2 == 0, "convgemm: stats need even chan_mod");
@@ -271,18 +476,18 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
     ASW_CHECK_ARG(a.ln_beta != nullptr, "convgemm: LayerNorm needs beta");
     ASW_CHECK_ARG(!stats, "convgemm: LayerNorm + stats epilogue is not a reference layer");
     switch (a.N) {
-      case 64: return launch<256, 64, 32, 4, 1, true, false>(a, s);
-      case 128: return launch<128, 128, 32, 2, 2, true, false>(a, s);
-      case 256: return launch<64, 256, 32, 1, 4, true, false>(a, s);
-      case 512: return launch<64, 512, 16, 1, 4, true, false>(a, s);
-      case 1024: return launch<32, 1024, 16, 1, 4, true, false>(a, s);
+      case 64: return launch_prec<256, 64, 32, 4, 1, true, false>(a, s);
+      case 128: return launch_prec<128, 128, 32, 2, 2, true, false>(a, s);
+      case 256: return launch_prec<64, 256, 32, 1, 4, true, false>(a, s);
+      case 512: return launch_prec<64, 512, 16, 1, 4, true, false>(a, s);
+      case 1024: return launch_prec<32, 1024, 16, 1, 4, true, false>(a, s);
       default:
         return asw::set_error(ASW_ERR_ARG, "convgemm: LayerNorm width %d unsupported (64..1024, power of 2)", a.N);
     }
   }
   if (wide_tile(a.N)) {
-    return stats ? launch<128, 128, 32, 2, 2, false, true>(a, s) : launch<128, 128, 32, 2, 2, false, false>(a, s);
+    return stats ? launch_prec<128, 128, 32, 2, 2, false, true>(a, s) : launch_prec<128, 128, 32, 2, 2, false, false>(a, s);
   }
   ASW_CHECK_ARG(a.N % 64 == 0, "convgemm: N=%d must be a multiple of 64", a.N);
-  return stats ? launch<256, 64, 32, 4, 1, false, true>(a, s) : launch<256, 64, 32, 4, 1, false, false>(a, s);
+  return stats ? launch_prec<256, 64, 32, 4, 1, false, true>(a, s) : launch_prec<256, 64, 32, 4, 1, false, false>(a, s);
 }

@@ -21,6 +21,10 @@ namespace {
 struct DevBuf {
   float* p = nullptr;
   size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
   ~DevBuf() { if (p) (void)hipFree(p); }
   int upload(const std::vector<float>& h) {
     if (p) { (void)hipFree(p); p = nullptr; }
@@ -31,14 +35,45 @@ struct DevBuf {
   }
 };
 
-struct ResLayer { DevBuf wt, bias, g, b; int dil = 1; };
+// A GEMM weight in both arithmetic forms: fp32 (exact f32 MFMA) and the fp16 hi/lo split
+// with its power-of-two pre-scale (f16x3 MFMA), see convgemm.hip.
+struct WBuf {
+  DevBuf f32;
+  uint16_t* hi = nullptr;
+  uint16_t* lo = nullptr;
+  int32_t shift = 0;
+  WBuf() = default;
+  WBuf(const WBuf&) = delete;
+  WBuf& operator=(const WBuf&) = delete;
+  WBuf(WBuf&& o) noexcept : f32(std::move(o.f32)), hi(o.hi), lo(o.lo), shift(o.shift) { o.hi = o.lo = nullptr; }
+  ~WBuf() { if (hi) (void)hipFree(hi); if (lo) (void)hipFree(lo); }
+  int upload(const std::vector<float>& h) {
+    int rc = f32.upload(h);
+    if (rc) return rc;
+    std::vector<uint16_t> vh(h.size()), vl(h.size());
+    if ((rc = asw_split_weights_f16(h.data(), h.size(), vh.data(), vl.data(), &shift))) return rc;
+    if (hi) { (void)hipFree(hi); hi = nullptr; }
+    if (lo) { (void)hipFree(lo); lo = nullptr; }
+    if (hipMalloc(&hi, h.size() * 2) != hipSuccess || hipMalloc(&lo, h.size() * 2) != hipSuccess)
+      return asw::set_error(ASW_ERR_NOMEM, "hipMalloc(%zu halves)", h.size());
+    ASW_HIP(hipMemcpy(hi, vh.data(), h.size() * 2, hipMemcpyHostToDevice));
+    ASW_HIP(hipMemcpy(lo, vl.data(), h.size() * 2, hipMemcpyHostToDevice));
+    return ASW_OK;
+  }
+  void bind(asw_convgemm_args& a, int precision) const {
+    a.Wt = f32.p; a.Wt_hi = hi; a.Wt_lo = lo; a.w_shift = shift; a.precision = precision;
+  }
+};
+
+struct ResLayer { WBuf wt; DevBuf bias, g, b; int dil = 1; };
 struct EncBlock { std::vector<ResLayer> res; DevBuf bias, gn_g, gn_b; int cin = 0, cout = 0, stride = 1; };
 struct DecBlock { std::vector<ResLayer> res; DevBuf gn_g, gn_b; int cin = 0, cout = 0, stride = 1; };
-struct TfLayer { DevBuf w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1g, n1b, n2g, n2b; };
+struct TfLayer { WBuf w_in, w_out, w1, w2; DevBuf b_in, b_out, b1, b2, n1g, n1b, n2g, n2b; };
 // window-embedding dependent weights (gate folded in)
 struct GateSet {
-  std::vector<std::unique_ptr<DevBuf>> down_wt;   // per encoder block
-  std::vector<std::unique_ptr<DevBuf>> up_wt, up_bias;  // per decoder block
+  std::vector<std::unique_ptr<WBuf>> down_wt;   // per encoder block
+  std::vector<std::unique_ptr<WBuf>> up_wt;     // per decoder block
+  std::vector<std::unique_ptr<DevBuf>> up_bias;
 };
 struct Tap { const float* p; size_t numel; };
 
@@ -59,7 +94,9 @@ struct asw_spot {
   std::vector<EncBlock> enc;
   std::vector<DecBlock> dec;
   std::vector<TfLayer> tf;
-  DevBuf byp_wt, byp_b, mask_wt, mask_b, dec_wt;
+  WBuf byp_wt, mask_wt, dec_wt;
+  DevBuf byp_b, mask_b;
+  int precision = 0;                       // 0 = exact f32 MFMA, 1 = f16x3 split MFMA
   float out_bias = 0.f;
   int byp_k = 0;                           // padded K of the bypass GEMM
   std::map<std::pair<float, float>, std::unique_ptr<GateSet>> gates;
@@ -183,7 +220,7 @@ int get_gates(asw_spot* m, float w0, float w1, GateSet** out) {
   for (int i = 0; i < c.depth; ++i) {
     const std::string p = "encoder.module_list." + std::to_string(i);
     const std::vector<float> g = gate_of(P(m, p + ".embed1.weight"), P(m, p + ".embed1.bias"), w0, w1);
-    gs->down_wt.emplace_back(new DevBuf());
+    gs->down_wt.emplace_back(new WBuf());
     int rc = gs->down_wt.back()->upload(
         pack_conv(P(m, p + ".conv1.weight"), 2 * m->enc_cout[i], m->enc_cin[i], c.kernel_size, g.data()));
     if (rc) return rc;
@@ -203,7 +240,7 @@ int get_gates(asw_spot* m, float w0, float w1, GateSet** out) {
         for (int cc = 0; cc < ci; ++cc)
           wt[((size_t)r * co2 + n) * ci + cc] = w[((size_t)cc * co2 + n) * s + r] * g[n];
       }
-    gs->up_wt.emplace_back(new DevBuf());
+    gs->up_wt.emplace_back(new WBuf());
     gs->up_bias.emplace_back(new DevBuf());
     int rc;
     if ((rc = gs->up_wt.back()->upload(wt))) return rc;
@@ -298,14 +335,14 @@ int ensure_ws(asw_spot* m, int B, int T, Plan& pl) {
   return ASW_OK;
 }
 
-int run_res(const std::vector<ResLayer>& res, int B, int T, int ch, int K, float* x, float* p, float* q,
+int run_res(const std::vector<ResLayer>& res, int prec, int B, int T, int ch, int K, float* x, float* p, float* q,
             float** final_out, hipStream_t s) {
   // ping-pong: layer 0 reads x (kept intact), later layers alternate p/q
   const float* in = x;
   float* outb = p;
   for (size_t j = 0; j < res.size(); ++j) {
     asw_convgemm_args a = {};
-    a.A = in; a.Wt = res[j].wt.p; a.bias = res[j].bias.p; a.resid = in;
+    a.A = in; res[j].wt.bind(a, prec); a.bias = res[j].bias.p; a.resid = in;
     a.ln_gamma = res[j].g.p; a.ln_beta = res[j].b.p; a.out = outb;
     a.B = B; a.M_out = T; a.N = ch; a.Cin = ch; a.taps = K; a.stride = 1; a.dil = res[j].dil;
     a.pad = (res[j].dil * (K - 1) + 1) / 2;
@@ -320,10 +357,10 @@ int run_res(const std::vector<ResLayer>& res, int B, int T, int ch, int K, float
   return ASW_OK;
 }
 
-int linear(const float* A, const float* W, const float* bias, int rows, int N, int K, int relu, const float* resid,
+int linear(const float* A, const WBuf& W, int prec, const float* bias, int rows, int N, int K, int relu, const float* resid,
            const float* g, const float* b, float* out, hipStream_t s) {
   asw_convgemm_args a = {};
-  a.A = A; a.Wt = W; a.bias = bias; a.resid = resid; a.ln_gamma = g; a.ln_beta = b; a.out = out;
+  a.A = A; W.bind(a, prec); a.bias = bias; a.resid = resid; a.ln_gamma = g; a.ln_beta = b; a.out = out;
   a.B = 1; a.M_out = rows; a.N = N; a.Cin = K; a.taps = 1; a.stride = 1; a.dil = 1; a.pad = 0;
   a.a_row_stride = K; a.a_batch_stride = (int64_t)rows * K; a.a_len = (int64_t)rows * K;
   a.relu = relu; a.ln_eps = 1e-5f;
@@ -341,9 +378,9 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
   // ---- encoder (network.py:98-113,146-156)
   for (int i = 0; i < c.depth; ++i) {
     float* r = nullptr;
-    if ((rc = run_res(m->enc[i].res, B, pl.Tl[i], m->enc_cin[i], K, pl.X[i], pl.Pb[i], pl.Qb[i], &r, s))) return rc;
+    if ((rc = run_res(m->enc[i].res, m->precision, B, pl.Tl[i], m->enc_cin[i], K, pl.X[i], pl.Pb[i], pl.Qb[i], &r, s))) return rc;
     asw_convgemm_args a = {};
-    a.A = r; a.Wt = gs->down_wt[i]->p; a.bias = m->enc[i].bias.p; a.out = pl.raw_dn[i]; a.stats = pl.st_dn[i];
+    a.A = r; gs->down_wt[i]->bind(a, m->precision); a.bias = m->enc[i].bias.p; a.out = pl.raw_dn[i]; a.stats = pl.st_dn[i];
     a.B = B; a.M_out = pl.Tl[i + 1]; a.N = 2 * m->enc_cout[i]; a.Cin = m->enc_cin[i]; a.taps = K;
     a.stride = c.stride_list[i]; a.dil = 1; a.pad = K / 2;
     a.a_row_stride = a.Cin; a.a_batch_stride = (int64_t)pl.Tl[i] * a.Cin; a.a_len = a.a_batch_stride;
@@ -360,11 +397,11 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
   for (int l = 0; l < c.num_transformer_layers; ++l) {
     TfLayer& t = m->tf[l];
     float* hout = (l % 2 == 0) ? pl.ha : pl.hb;
-    if ((rc = linear(h, t.w_in.p, t.b_in.p, rows, 3 * d, d, 0, nullptr, nullptr, nullptr, pl.qkv, s))) return rc;
+    if ((rc = linear(h, t.w_in, m->precision, t.b_in.p, rows, 3 * d, d, 0, nullptr, nullptr, nullptr, pl.qkv, s))) return rc;
     if ((rc = asw_attention(pl.qkv, B, L, d, c.num_head, pl.ctx, s))) return rc;
-    if ((rc = linear(pl.ctx, t.w_out.p, t.b_out.p, rows, d, d, 0, h, t.n1g.p, t.n1b.p, pl.x1, s))) return rc;
-    if ((rc = linear(pl.x1, t.w1.p, t.b1.p, rows, c.ffw_dim, d, 1, nullptr, nullptr, nullptr, pl.ff, s))) return rc;
-    if ((rc = linear(pl.ff, t.w2.p, t.b2.p, rows, d, c.ffw_dim, 0, pl.x1, t.n2g.p, t.n2b.p, hout, s))) return rc;
+    if ((rc = linear(pl.ctx, t.w_out, m->precision, t.b_out.p, rows, d, d, 0, h, t.n1g.p, t.n1b.p, pl.x1, s))) return rc;
+    if ((rc = linear(pl.x1, t.w1, m->precision, t.b1.p, rows, c.ffw_dim, d, 1, nullptr, nullptr, nullptr, pl.ff, s))) return rc;
+    if ((rc = linear(pl.ff, t.w2, m->precision, t.b2.p, rows, d, c.ffw_dim, 0, pl.x1, t.n2g.p, t.n2b.p, hout, s))) return rc;
     h = hout;
   }
   m->taps["bottleneck"] = {h, (size_t)rows * d};
@@ -373,7 +410,7 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
   for (int j = 0; j < c.depth; ++j) {
     const int lvl = c.depth - j, ci = m->dec_cin[j], co = m->dec_cout[j], st = m->dec_stride[j];
     asw_convgemm_args a = {};
-    a.A = x; a.A2 = pl.X[lvl]; a.Wt = gs->up_wt[j]->p; a.bias = gs->up_bias[j]->p; a.out = pl.raw_up[j];
+    a.A = x; a.A2 = pl.X[lvl]; gs->up_wt[j]->bind(a, m->precision); a.bias = gs->up_bias[j]->p; a.out = pl.raw_up[j];
     a.stats = pl.st_up[j];
     a.B = B; a.M_out = pl.Tl[lvl]; a.N = st * 2 * co; a.Cin = ci; a.taps = 1; a.stride = 1; a.dil = 1; a.pad = 0;
     a.a_row_stride = ci; a.a_batch_stride = (int64_t)pl.Tl[lvl] * ci; a.a_len = a.a_batch_stride;
@@ -386,7 +423,7 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
       return rc;
     float* r = nullptr;
     // residual ping-pong: g -> P -> g -> P ...
-    if ((rc = run_res(m->dec[j].res, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s))) return rc;
+    if ((rc = run_res(m->dec[j].res, m->precision, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s))) return rc;
     x = r;
     m->taps["dec" + std::to_string(j)] = {x, (size_t)B * To * co};
   }
@@ -394,14 +431,14 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
   const int E = c.encoder_channels, EK = c.encoder_kernel_size, ES = c.encoder_stride;
   {
     asw_convgemm_args a = {};   // reference_bypass: rows of the padded reference channel, hop ES
-    a.A = pl.refn; a.Wt = m->byp_wt.p; a.bias = m->byp_b.p; a.out = pl.Y;
+    a.A = pl.refn; m->byp_wt.bind(a, m->precision); a.bias = m->byp_b.p; a.out = pl.Y;
     a.B = B; a.M_out = pl.F; a.N = E; a.Cin = m->byp_k; a.taps = 1; a.stride = 1; a.dil = 1; a.pad = 0;
     a.a_row_stride = ES; a.a_batch_stride = pl.RL; a.a_len = pl.RL; a.relu = 1;
     if ((rc = asw_convgemm_f32(&a, s))) return rc;
   }
   {
     asw_convgemm_args a = {};   // mask_encoder, ReLU, times the bypass latent (in place)
-    a.A = x; a.Wt = m->mask_wt.p; a.bias = m->mask_b.p; a.mul = pl.Y; a.out = pl.Y;
+    a.A = x; m->mask_wt.bind(a, m->precision); a.bias = m->mask_b.p; a.mul = pl.Y; a.out = pl.Y;
     a.B = B; a.M_out = pl.F; a.N = E; a.Cin = c.channels; a.taps = EK; a.stride = ES; a.dil = 1; a.pad = EK / 2;
     a.a_row_stride = c.channels; a.a_batch_stride = (int64_t)pl.Tp * c.channels; a.a_len = a.a_batch_stride;
     a.relu = 1;
@@ -410,7 +447,7 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
   m->taps["latent"] = {pl.Y, (size_t)B * pl.F * E};
   {
     asw_convgemm_args a = {};   // output_decoder taps: D[f][j] = sum_e latent[f][e] * w[e][j]
-    a.A = pl.Y; a.Wt = m->dec_wt.p; a.out = pl.D;
+    a.A = pl.Y; m->dec_wt.bind(a, m->precision); a.out = pl.D;
     a.B = B; a.M_out = pl.F; a.N = 64; a.Cin = E; a.taps = 1; a.stride = 1; a.dil = 1; a.pad = 0;
     a.a_row_stride = E; a.a_batch_stride = (int64_t)pl.F * E; a.a_len = a.a_batch_stride;
     if ((rc = asw_convgemm_f32(&a, s))) return rc;
@@ -472,6 +509,12 @@ extern "C" int asw_spot_create(const asw_spot_config* cfg, asw_spot** out) {
 }
 
 extern "C" void asw_spot_destroy(asw_spot* m) { delete m; }
+
+extern "C" int asw_spot_set_precision(asw_spot* m, int precision) {
+  ASW_CHECK_ARG(m && (precision == 0 || precision == 1), "set_precision: 0 (f32) or 1 (f16x3)");
+  m->precision = precision;
+  return ASW_OK;
+}
 
 extern "C" int asw_spot_set_batch(asw_spot* m, int batch) {
   ASW_CHECK_ARG(m && batch >= 1 && batch <= 4096, "set_batch: bad argument");

@@ -25,7 +25,7 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, relu=False, resid=None, mul=None,
              ln=None, stats_chan_mod=0, A2=None, B=None, a_row_stride=None, a_batch_stride=None, a_len=None,
-             out=None, ln_eps=1e-5):
+             out=None, ln_eps=1e-5, precision="f32"):
     """out[b][r][n] per include/asw_hip.h:asw_convgemm_f32.  Returns (out, stats|None)."""
     _f32(A); _f32(Wt)
     if B is None:
@@ -53,8 +53,29 @@ def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, re
     a.B, a.M_out, a.N, a.Cin, a.taps, a.stride, a.dil, a.pad = B, M_out, N, Cin, taps, stride, dil, pad
     a.a_row_stride, a.a_batch_stride, a.a_len = a_row_stride, a_batch_stride, a_len
     a.chan_mod, a.relu, a.ln_eps = stats_chan_mod, int(relu), ln_eps
+    keep = None
+    if precision == "f16x3":
+        hi, lo, shift = split_weights_f16(Wt)
+        keep = (hi, lo)
+        a.precision, a.w_shift, a.Wt_hi, a.Wt_lo = 1, shift, hi.data_ptr(), lo.data_ptr()
     check(lib().asw_convgemm_f32(byref(a), current_stream()))
+    torch.cuda.current_stream().synchronize() if keep is not None else None
     return out, stats
+
+
+def split_weights_f16(Wt):
+    """fp32 device weights -> (hi, lo) fp16-bit uint16 device tensors + power-of-two shift,
+    through the library's own host splitter (asw_split_weights_f16)."""
+    import ctypes
+    import numpy as np
+    w = np.ascontiguousarray(Wt.detach().cpu().numpy(), dtype=np.float32)
+    hi = np.empty(w.size, dtype=np.uint16)
+    lo = np.empty(w.size, dtype=np.uint16)
+    sh = ctypes.c_int32()
+    check(lib().asw_split_weights_f16(ctypes.c_void_p(w.ctypes.data), w.size, ctypes.c_void_p(hi.ctypes.data),
+                                      ctypes.c_void_p(lo.ctypes.data), byref(sh)))
+    dev = Wt.device
+    return (torch.from_numpy(hi.view(np.int16)).to(dev), torch.from_numpy(lo.view(np.int16)).to(dev), sh.value)
 
 
 def gn_glu(raw, stats, gamma, beta, eps=1e-5):

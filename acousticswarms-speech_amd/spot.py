@@ -28,8 +28,15 @@ def offsets_from_patches(patch_list, n_pairs: int) -> np.ndarray:
 
 
 class SpotModel:
-    def __init__(self, cfg: SpotConfig = FULL, state_dict=None, batch_size: int = 32):
+    PRECISIONS = {"f32": 0, "f16x3": 1}
+
+    def __init__(self, cfg: SpotConfig = FULL, state_dict=None, batch_size: int = 32, precision: str = "f32"):
+        """precision: "f32" = exact fp32 MFMA; "f16x3" = split-operand half MFMA with fp32
+        accumulation (~21-bit operands, 5.3x the f32 matrix rate), see csrc/convgemm.hip."""
+        if precision not in self.PRECISIONS:
+            raise RuntimeError(f"precision must be one of {list(self.PRECISIONS)}")
         self.cfg = cfg
+        self.precision = precision
         self.batch_size = batch_size
         self.device = None
         self._h = None
@@ -86,6 +93,7 @@ class SpotModel:
         native.check(L.asw_spot_create(byref(cc), byref(h)))
         self._h = h
         native.check(L.asw_spot_set_batch(self._h, int(self.batch_size)))
+        native.check(L.asw_spot_set_precision(self._h, self.PRECISIONS[self.precision]))
         self.device = device
         if self._sd is not None:
             self._upload()
@@ -93,6 +101,13 @@ class SpotModel:
 
     def eval(self):
         return self
+
+    def set_precision(self, precision: str):
+        if precision not in self.PRECISIONS:
+            raise RuntimeError(f"precision must be one of {list(self.PRECISIONS)}")
+        self.precision = precision
+        if self._h is not None:
+            native.check(native.lib().asw_spot_set_precision(self._h, self.PRECISIONS[precision]))
 
     def set_batch_size(self, b: int):
         self.batch_size = int(b)

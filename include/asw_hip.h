@@ -81,6 +81,10 @@ int asw_spot_finalize(asw_spot* m);
  * spot_batch_size, sep/training/JointModel/network.py:28,75). */
 int asw_spot_set_batch(asw_spot* m, int batch);
 
+/* Arithmetic of the GEMM-class layers: 0 = exact fp32 MFMA (default), 1 = "f16x3"
+ * split-operand half MFMA with fp32 accumulation (see asw_convgemm_args.precision). */
+int asw_spot_set_precision(asw_spot* m, int precision);
+
 /* The hot loop: replaces DataParallelSpotModel.shift_and_sep
  * (sep/training/JointModel/network.py:37-104): for each of the N candidates,
  * circularly advance channel m>=1 of `mix` by offsets[n][m-1] samples, int16-quantise
@@ -158,8 +162,22 @@ typedef struct asw_convgemm_args {
   int32_t chan_mod;       /* stats: group = ((n % chan_mod) >= chan_mod/2) */
   int32_t relu;
   float ln_eps;
+  /* precision 0: Wt is fp32 and the products run on the exact f32 MFMA.
+   * precision 1 ("f16x3"): every fp32 operand x is split into two halves
+   *   hi = fp16(x), lo = fp16(x - hi) and the product is hi*hi + hi*lo + lo*hi on the f16
+   *   MFMA with fp32 accumulation (operands good to ~2^-21, 5.3x the f32 MFMA rate).
+   *   Weights arrive pre-split: Wt_hi / Wt_lo are fp16 [N][taps*Cin] of (w * 2^w_shift);
+   *   activations are split on the fly (saturated at +-65504). */
+  int32_t precision;
+  int32_t w_shift;
+  const void* Wt_hi;
+  const void* Wt_lo;
 } asw_convgemm_args;
 int asw_convgemm_f32(const asw_convgemm_args* args, void* stream);
+/* Host helper: split n fp32 weights into the fp16 hi/lo pair used by precision 1 with the
+ * power-of-two pre-scale that keeps the lo parts out of the fp16 subnormal range; returns
+ * the shift through *w_shift.  hi/lo: n uint16 each (host). */
+int asw_split_weights_f16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, int32_t* w_shift);
 /* Number of stats partials per batch item the call above will write. */
 int asw_convgemm_stats_tiles(int M_out, int N);
 

@@ -1,0 +1,116 @@
+"""Parity of the "f16x3" split-operand MFMA mode (csrc/convgemm.hip, precision 1) -- the
+fast arithmetic of the GEMM-class layers.  Same references and same end-to-end bar as the
+exact-f32 mode (>= 80 dB SNR against the reference's own outputs; north-star tolerance:
+SI-SDR within 0.1 dB); per-kernel tolerance 2e-5 relative L2 (operands carry ~21 bits).
+Needs an MI355X."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _log(msg):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "diag_f16x3.txt"), "a") as f:
+        f.write(msg + "\n")
+    print(msg)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm())
+
+
+def snr_db(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return 10 * np.log10(np.sum(ref ** 2) / max(np.sum((got - ref) ** 2), 1e-300))
+
+
+@pytest.mark.parametrize("C,T,dil", [(64, 1000, 1), (64, 900, 49), (128, 520, 7), (256, 300, 49), (512, 130, 7)])
+def test_residual_layer_f16x3(C, T, dil):
+    from acousticswarms_speech_amd import ops
+    B, K = 2, 7
+    x = _rand(B, C, T, seed=3)
+    w = _rand(C, C, K, seed=4, scale=1.0 / math.sqrt(C * K))
+    b, g, be = _rand(C, seed=5, scale=0.1), 1 + _rand(C, seed=6, scale=0.1), _rand(C, seed=7, scale=0.1)
+    want = F.layer_norm((F.relu(F.conv1d(x, w, b, dilation=dil, padding=3 * dil)) + x).transpose(1, 2), (C,), g, be)
+    xc = x.transpose(1, 2).contiguous().cuda()
+    out, _ = ops.convgemm(xc, ops.pack_conv_weight(w).cuda(), T, C, C, taps=K, dil=dil, pad=3 * dil, bias=b.cuda(),
+                          relu=True, resid=xc, ln=(g.cuda(), be.cuda()), precision="f16x3")
+    r = _rel(out.cpu(), want)
+    _log(f"f16x3 res C={C} dil={dil}: rel={r:.3e}")
+    assert r < 2e-5
+
+
+def test_wide_and_scaled_operands_f16x3():
+    """Plain / stats tiles; operands far from unit scale (tiny weights, large activations,
+    values beyond the fp16 range saturate instead of turning into inf/NaN)."""
+    from acousticswarms_speech_amd import ops
+    B, T, Cin, N = 2, 300, 128, 256
+    for wscale, xscale in ((1e-3, 1.0), (1.0, 300.0), (30.0, 1e-2)):
+        x = _rand(B, T, Cin, seed=8, scale=xscale)
+        w = _rand(N, Cin, seed=9, scale=wscale / math.sqrt(Cin))
+        want = F.linear(x, w)
+        out, st = ops.convgemm(x.cuda(), w.cuda(), T, N, Cin, stats_chan_mod=N, precision="f16x3")
+        r = _rel(out.cpu(), want)
+        _log(f"f16x3 wide wscale={wscale} xscale={xscale}: rel={r:.3e}")
+        assert r < 2e-5
+        s = st.cpu().double().sum(1)
+        np.testing.assert_allclose(s[:, 0].numpy(), want[..., :N // 2].double().sum((1, 2)).numpy(), rtol=1e-3, atol=1e-2)
+    x = _rand(1, 256, 64, seed=10)
+    x[0, 0, 0] = 1e6                                   # beyond fp16: saturates to 65504
+    out, _ = ops.convgemm(x.cuda(), _rand(64, 64, seed=11).cuda(), 256, 64, 64, precision="f16x3")
+    assert torch.isfinite(out).all()
+
+
+def _model(cfg, seed, batch=32):
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    return SpotModel(cfg, make_spot_state_dict(cfg, seed), batch_size=batch, precision="f16x3").to("cuda")
+
+
+def test_forward_full_f16x3_vs_reference_golden(golden):
+    from acousticswarms_speech_amd.config import FULL
+    g = golden("g3_spot_full")
+    m = _model(FULL, 5)
+    rng = np.random.default_rng(31)
+    x = torch.from_numpy(rng.standard_normal((2, 7, 12288)).astype(np.float32))
+    y = m.forward(x, torch.tensor([[0.0, 1.0]] * 2)).cpu().numpy()
+    s = snr_db(y, g["y"])
+    _log(f"f16x3 full forward: SNR vs reference {s:.1f} dB")
+    for k in ["bottleneck", "dec4"]:
+        probe, idx = g[f"{k}_probe"], g[f"{k}_idx"]
+        tap = m.get_tap(k).cpu().numpy().reshape(2, -1, probe.shape[1])
+        _log(f"f16x3 tap {k}: probe SNR {snr_db(tap[:, idx, :].transpose(0, 2, 1), probe):.1f} dB")
+    assert s > 80.0
+
+
+def test_shift_and_sep_full_f16x3_vs_reference_golden(golden):
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.scenes import make_scene
+    from oracle import spot_ref
+    g = golden("g4b_shift_and_sep_full")
+    m = _model(FULL, 5, batch=4)
+    mix = torch.from_numpy(make_scene(2, 3, 7, 6000).mix)
+    for strict in (0, 1):
+        y = m.shift_and_sep(mix, list(g["offsets"]), Strict=strict)
+        ref = g[f"y_strict{strict}"]
+        per = [snr_db(y[i], ref[i]) for i in range(y.shape[0])]
+        _log(f"f16x3 shift_and_sep strict={strict}: per-candidate SNR {np.round(per, 1)}")
+        assert min(per) > 80.0
+        en = m.shift_and_score(mix, list(g["offsets"]), Strict=strict, window=1500)
+        np.testing.assert_allclose(en, spot_ref.candidate_energies(ref, 1500), rtol=1e-4)
+    m.set_precision("f32")
+    y32 = m.shift_and_sep(mix, list(g["offsets"]), Strict=1)
+    assert min(snr_db(y32[i], g["y_strict1"][i]) for i in range(5)) > 100.0
