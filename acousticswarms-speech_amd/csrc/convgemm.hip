@@ -52,7 +52,6 @@ __device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN /
                                          float* smem, float acc_scale) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDC = BN + 4;
-  constexpr int NQ = BN / 64;
   float* Ct = smem;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
@@ -75,45 +74,85 @@ __device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN /
       }
     }
     __syncthreads();
-    for (int sr = wid; sr < WM * 32; sr += 4) {
-      const int trow = (sr >> 5) * (BM / WM) + tm * 32 + (sr & 31);
-      const int t_out = m0 + trow;
-      if (t_out >= p.M_out) continue;           // wave-uniform
-      const long obase = ((long)b * p.M_out + t_out) * p.N + n0;
-      float v[NQ];
+    // Row phase.  A row is BN/4 float4; LPR lanes share a row (RPI rows per wave
+    // instruction, VPL float4 per lane), so each wave walks its 8*WM slab rows in 8 steps.
+    // Steps are processed four at a time with every global load (residual / gate tensor)
+    // issued before the first use: the loads of four steps overlap instead of serialising.
+    constexpr int LPR = (BN / 4 < 64) ? BN / 4 : 64;
+    constexpr int RPI = 64 / LPR;
+    constexpr int VPL = BN / 4 / LPR;
+    constexpr int UNR = 4;
+    const int sub = lane / LPR, lc = lane % LPR;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int col = lane + 64 * q;
-        float x = Ct[sr * LDC + col];
-        if (p.resid) x += p.resid[obase + col];
-        if (p.mul) x *= p.mul[obase + col];
-        v[q] = x;
-      }
-      if (LN) {
-        float s = 0.f;
+    for (int it0 = 0; it0 < 8; it0 += UNR) {
+      float4 v[UNR][VPL];
+      long obase[UNR];
+      bool ok[UNR];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) s += v[q];
-        const float mean = wave_sum(s) * (1.0f / BN);
-        float d = 0.f;
+      for (int u = 0; u < UNR; ++u) {
+        const int sr = ((it0 + u) * 4 + wid) * RPI + sub;
+        const int trow = (sr >> 5) * (BM / WM) + tm * 32 + (sr & 31);
+        const int t_out = m0 + trow;
+        ok[u] = t_out < p.M_out;
+        obase[u] = ((long)b * p.M_out + t_out) * p.N + n0;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { const float c = v[q] - mean; d += c * c; }
-        const float var = wave_sum(d) * (1.0f / BN);
-        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int col = lane + 64 * q;
-          v[q] = (v[q] - mean) * rstd * p.ln_gamma[col] + p.ln_beta[col];
+        for (int q = 0; q < VPL; ++q) {
+          const int col = (lc + q * LPR) * 4;
+          float4 x = *reinterpret_cast<const float4*>(Ct + sr * LDC + col);
+          if (ok[u]) {
+            if (p.resid) {
+              const float4 r = *reinterpret_cast<const float4*>(p.resid + obase[u] + col);
+              x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+            }
+            if (p.mul) {
+              const float4 g = *reinterpret_cast<const float4*>(p.mul + obase[u] + col);
+              x.x *= g.x; x.y *= g.y; x.z *= g.z; x.w *= g.w;
+            }
+          }
+          v[u][q] = x;
         }
       }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int col = lane + 64 * q;
-        if (STATS) {
-          const bool g1 = ((n0 + col) % p.chan_mod) >= half_mod;
-          const float x = v[q];
-          if (g1) { st1 += x; sq1 += x * x; } else { st0 += x; sq0 += x * x; }
+      for (int u = 0; u < UNR; ++u) {
+        if (LN) {
+          float s = 0.f;
+#pragma unroll
+          for (int q = 0; q < VPL; ++q) s += (v[u][q].x + v[u][q].y) + (v[u][q].z + v[u][q].w);
+#pragma unroll
+          for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+          const float mean = s * (1.0f / BN);
+          float d = 0.f;
+#pragma unroll
+          for (int q = 0; q < VPL; ++q) {
+            const float cx = v[u][q].x - mean, cy = v[u][q].y - mean, cz = v[u][q].z - mean, cw = v[u][q].w - mean;
+            d += (cx * cx + cy * cy) + (cz * cz + cw * cw);
+          }
+#pragma unroll
+          for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+          const float rstd = 1.0f / sqrtf(d * (1.0f / BN) + p.ln_eps);
+#pragma unroll
+          for (int q = 0; q < VPL; ++q) {
+            const int col = (lc + q * LPR) * 4;
+            const float4 g = *reinterpret_cast<const float4*>(p.ln_gamma + col);
+            const float4 be = *reinterpret_cast<const float4*>(p.ln_beta + col);
+            v[u][q].x = (v[u][q].x - mean) * rstd * g.x + be.x;
+            v[u][q].y = (v[u][q].y - mean) * rstd * g.y + be.y;
+            v[u][q].z = (v[u][q].z - mean) * rstd * g.z + be.z;
+            v[u][q].w = (v[u][q].w - mean) * rstd * g.w + be.w;
+          }
         }
-        p.out[obase + col] = v[q];
+        if (ok[u]) {
+#pragma unroll
+          for (int q = 0; q < VPL; ++q) {
+            const int col = (lc + q * LPR) * 4;
+            if (STATS) {
+              const float4 x = v[u][q];
+              const float s1 = (x.x + x.y) + (x.z + x.w), s2 = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+              if (((n0 + col) % p.chan_mod) >= half_mod) { st1 += s1; sq1 += s2; } else { st0 += s1; sq0 += s2; }
+            }
+            *reinterpret_cast<float4*>(p.out + obase[u] + col) = v[u][q];
+          }
+        }
       }
     }
   }
