@@ -47,15 +47,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------ shared epilogue
-template <int BM, int BN, int WM, int WN, bool LN, bool STATS>
+// tile row -> output row of the batch item (or -1): contiguous tiles
+struct RowsContig {
+  int m0, M;
+  __device__ __forceinline__ int operator()(int trow) const { const int t = m0 + trow; return t < M ? t : -1; }
+};
+
+template <int BM, int BN, int WM, int WN, bool LN, bool STATS, typename RowMap>
 __device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
-                                         float* smem, float acc_scale) {
+                                         float* smem, float acc_scale, const RowMap& rowmap) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDC = BN + 4;
   float* Ct = smem;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int b = blockIdx.z, n0 = blockIdx.y * BN;
   float st0 = 0.f, sq0 = 0.f, st1 = 0.f, sq1 = 0.f;
   const int half_mod = p.chan_mod >> 1;
 #pragma unroll
@@ -92,8 +98,8 @@ __device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN /
       for (int u = 0; u < UNR; ++u) {
         const int sr = ((it0 + u) * 4 + wid) * RPI + sub;
         const int trow = (sr >> 5) * (BM / WM) + tm * 32 + (sr & 31);
-        const int t_out = m0 + trow;
-        ok[u] = t_out < p.M_out;
+        const int t_out = rowmap(trow);
+        ok[u] = t_out >= 0;
         obase[u] = ((long)b * p.M_out + t_out) * p.N + n0;
 #pragma unroll
         for (int q = 0; q < VPL; ++q) {
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p
       }
     }
   }
-  epilogue<BM, BN, WM, WN, LN, STATS>(acc, p, smem, 1.0f);
+  epilogue<BM, BN, WM, WN, LN, STATS>(acc, p, smem, 1.0f, RowsContig{m0, p.M_out});
 }
 
 // ------------------------------------------------------------------ f16x3 split MFMA
@@ -422,7 +428,203 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args
         }
     }
   }
-  epilogue<BM, BN, WM, WN, LN, STATS>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift));
+  epilogue<BM, BN, WM, WN, LN, STATS>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out});
+}
+
+// ------------------------------------------------------------------ halo-staged residual conv
+// DilatedResidualLayer (network.py:57-68) in f16x3 arithmetic: out = LN(ReLU(conv_d(x)+b) + x).
+// The workgroup owns BM output rows x all C channels.  For each 64-channel slice of the
+// input it stages the rows its taps touch ONCE into LDS, already split into fp16 hi/lo
+// (row = 128 B hi + 128 B lo + 16 B pad: the per-lane 16-byte fragment reads of 32
+// consecutive rows are bank-conflict free); every tap reads that image at a row offset, so
+// the input is fetched and converted once per workgroup instead of once per tap.
+//
+// Row sets.  PH == 1: BM consecutive rows, image = rows [m0 - pad, m0 + BM + pad), tap step
+// = dil rows.  PH > 1 (large dilation, 49): a dilated convolution is `dil` independent
+// dilation-1 convolutions on the polyphase sub-sequences x[phase + dil*j]; the workgroup
+// takes PH phases x BM/PH consecutive j, image = PH x (BM/PH + taps-1) rows, tap step = 1
+// row.  The halo is then K-1 rows per phase instead of (K-1)*dil, which keeps the image at
+// ~40 KB and lets 3-4 workgroups share a CU (the kernel is latency-bound otherwise).
+//
+// Weights never touch LDS: they are pre-packed in MFMA-fragment order, so each wave pulls
+// its B operand with one coalesced 1 KiB load per fragment, one k-step ahead of the MFMAs
+// (they are L2/L1-resident: a layer's weights are at most 7.3 MB and shared by every
+// workgroup).  No barrier inside the taps x k-steps of a slice.
+template <int BM, int PH>
+struct ResRows {
+  static constexpr int BMJ = BM / PH;
+  int m0, jb, pb, dil, T;                    // PH == 1 uses m0; PH > 1 uses (jb, pb)
+  __device__ __forceinline__ int operator()(int trow) const {
+    if (PH == 1) { const int t = m0 + trow; return t < T ? t : -1; }
+    const int ph = pb * PH + trow / BMJ;
+    const int t = dil * (jb * BMJ + trow % BMJ) + ph;
+    return (ph < dil && t < T) ? t : -1;
+  }
+};
+
+template <int BM, int C, int WM, int WN, int PH>
+__global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WM / 32, TN = C / WN / 32;
+  constexpr int RS = 272;                    // bytes per staged row: 128 hi + 128 lo + 16 pad
+  constexpr int NT = C / 32;                 // 32-column fragments across N
+  constexpr int BMJ = BM / PH;
+  static_assert(BMJ % 32 == 0, "an MFMA row tile must stay inside one phase");
+
+  extern __shared__ __align__(16) float smem[];
+  char* img = reinterpret_cast<char*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int b = blockIdx.z;
+  const int taps = p.taps, dil = p.dil, pad = p.pad;
+  const int T = p.M_out;
+  // PH == 1: blockIdx.x = row tile.  PH > 1: blockIdx.x = jb * n_pb + pb.
+  const int n_pb = (dil + PH - 1) / PH;
+  const int jb = PH == 1 ? 0 : blockIdx.x / n_pb, pb = PH == 1 ? 0 : blockIdx.x % n_pb;
+  const int m0 = blockIdx.x * BM;
+  const int RJ = BMJ + (PH == 1 ? (taps - 1) * dil : taps - 1);   // image rows per phase
+  const int R = PH * RJ;
+  const int tapstep = PH == 1 ? dil : 1;
+  const float* __restrict__ xb = p.A + (long)b * p.a_batch_stride;
+  const half8* __restrict__ Wh = reinterpret_cast<const half8*>(p.Wf_hi);
+  const half8* __restrict__ Wl = reinterpret_cast<const half8*>(p.Wf_lo);
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int srow = tid >> 4, sc4 = tid & 15;          // staging: 16 threads per row, 16 rows per pass
+  int a_base[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int trow = wm * (BM / WM) + i * 32;          // first row of this MFMA tile
+    a_base[i] = ((trow / BMJ) * RJ + trow % BMJ + (lane & 31)) * RS + (lane >> 5) * 16;
+  }
+  const int nt0 = wn * TN;                            // first N fragment of this wave
+
+  for (int cc = 0; cc < C / 64; ++cc) {
+    __syncthreads();                                   // previous slice fully consumed
+    // ---- stage + split the image of this channel slice (8 rows per thread in flight)
+    for (int r0 = 0; r0 < R; r0 += 16 * 8) {
+      float4 buf[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = r0 + u * 16 + srow;
+        int g;
+        bool ok = row < R;
+        if (PH == 1) {
+          g = m0 - pad + row;
+        } else {
+          const int ph = pb * PH + row / RJ;
+          g = dil * (jb * BMJ + row % RJ - (taps - 1) / 2) + ph;
+          ok = ok && ph < dil && (jb * BMJ + row % RJ - (taps - 1) / 2) >= 0;
+        }
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && g >= 0 && g < T) x = *reinterpret_cast<const float4*>(xb + (long)g * C + cc * 64 + sc4 * 4);
+        buf[u] = x;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = r0 + u * 16 + srow;
+        if (row < R) {
+          half4 hi, lo;
+          split4(buf[u], hi, lo);
+          *reinterpret_cast<half4*>(img + row * RS + sc4 * 8) = hi;
+          *reinterpret_cast<half4*>(img + row * RS + 128 + sc4 * 8) = lo;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- taps x k-steps, B fragments double-buffered in registers
+    half8 bh0[TN], bl0[TN], bh1[TN], bl1[TN];
+    auto bload = [&](int tap, int ks, half8 (&bh)[TN], half8 (&bl)[TN]) {
+      const long kg = (long)tap * (C / 16) + cc * 4 + ks;          // global k-step
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const long o = (kg * NT + nt0 + j) * 64 + lane;
+        bh[j] = Wh[o];
+        bl[j] = Wl[o];
+      }
+    };
+    auto compute = [&](int tap, int ks, const half8 (&bh)[TN], const half8 (&bl)[TN]) {
+      half8 ah[TM], al[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const char* q = img + a_base[i] + tap * tapstep * RS + ks * 32;
+        ah[i] = *reinterpret_cast<const half8*>(q);
+        al[i] = *reinterpret_cast<const half8*>(q + 128);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    bload(0, 0, bh0, bl0);
+    for (int tap = 0; tap < taps; ++tap) {
+      bload(tap, 1, bh1, bl1);
+      compute(tap, 0, bh0, bl0);
+      bload(tap, 2, bh0, bl0);
+      compute(tap, 1, bh1, bl1);
+      bload(tap, 3, bh1, bl1);
+      compute(tap, 2, bh0, bl0);
+      if (tap + 1 < taps) bload(tap + 1, 0, bh0, bl0);
+      compute(tap, 3, bh1, bl1);
+    }
+  }
+  epilogue<BM, C, WM, WN, true, false>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
+                                       ResRows<BM, PH>{m0, jb, pb, dil, T});
+}
+
+template <int BM, int C, int WM, int WN, int PH>
+int launch_res(const asw_convgemm_args& a, hipStream_t s) {
+  constexpr int BMJ = BM / PH;
+  const int RJ = BMJ + (PH == 1 ? (a.taps - 1) * a.dil : a.taps - 1);
+  const size_t img = (size_t)PH * RJ * 272;
+  const size_t slab = (size_t)(WM * 32) * (C + 4) * sizeof(float);
+  const size_t smem = img > slab ? img : slab;
+  if (smem > 160 * 1024) return 1;                     // caller falls back to the generic kernel
+  auto kern = resconv16_kernel<BM, C, WM, WN, PH>;
+  static bool attr = false;
+  if (!attr) {
+    ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr = true;
+  }
+  const int gx = PH == 1 ? asw::cdiv(a.M_out, BM)
+                         : asw::cdiv(asw::cdiv(a.M_out, a.dil), BMJ) * asw::cdiv(a.dil, PH);
+  dim3 grid(gx, 1, a.B);
+  char nm[64];
+  snprintf(nm, sizeof nm, "resconv16<%d,%d,ph%d>", BM, C, PH);
+  asw::ProfScope prof(s, nm, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+// returns 1 when the layer is not a halo-kernel case (or does not fit LDS)
+int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
+  const bool shape = a.precision == 1 && a.Wf_hi && a.Wf_lo && a.ln_gamma && a.stride == 1 && a.taps > 1 &&
+                     a.taps % 2 == 1 && a.Cin == a.N && a.a_row_stride == a.Cin && a.resid == a.A && !a.A2 &&
+                     !a.mul && !a.stats && a.pad * 2 == (a.taps - 1) * a.dil &&
+                     a.a_len == (int64_t)a.M_out * a.Cin && a.a_batch_stride == a.a_len;
+  if (!shape) return 1;
+  const bool poly = a.dil >= 16;                       // large dilation: polyphase row sets
+  switch (a.N) {
+    case 64: return poly ? launch_res<128, 64, 4, 1, 4>(a, s) : launch_res<128, 64, 4, 1, 1>(a, s);
+    case 128: return poly ? launch_res<128, 128, 2, 2, 4>(a, s) : launch_res<128, 128, 2, 2, 1>(a, s);
+    case 256: return poly ? launch_res<64, 256, 1, 4, 2>(a, s) : launch_res<64, 256, 1, 4, 1>(a, s);
+    case 512: return poly ? launch_res<64, 512, 1, 4, 2>(a, s) : launch_res<64, 512, 1, 4, 1>(a, s);
+    default: return 1;
+  }
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool F16>
@@ -497,6 +699,28 @@ extern "C" int asw_split_weights_f16(const float* w, size_t n, uint16_t* hi, uin
   return ASW_OK;
 }
 
+extern "C" int asw_pack_fragments_f16(const float* Wt, int N, int K, uint16_t* hi, uint16_t* lo, int32_t* w_shift) {
+  ASW_CHECK_ARG(Wt && hi && lo && w_shift, "pack_fragments: null pointer");
+  ASW_CHECK_ARG(N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "pack_fragments: N %% 32, K %% 16 required (N=%d K=%d)", N, K);
+  const size_t n = (size_t)N * K;
+  uint16_t* th = new uint16_t[2 * n];
+  uint16_t* tl = th + n;
+  int rc = asw_split_weights_f16(Wt, n, th, tl, w_shift);
+  if (rc == ASW_OK) {
+    const int NT = N / 32;
+    for (int ks = 0; ks < K / 16; ++ks)
+      for (int nt = 0; nt < NT; ++nt)
+        for (int l = 0; l < 64; ++l) {
+          const size_t src = (size_t)(nt * 32 + (l & 31)) * K + ks * 16 + 8 * (l >> 5);
+          const size_t dst = (((size_t)ks * NT + nt) * 64 + l) * 8;
+          memcpy(hi + dst, th + src, 16);
+          memcpy(lo + dst, tl + src, 16);
+        }
+  }
+  delete[] th;
+  return rc;
+}
+
 extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
   ASW_CHECK_ARG(args != nullptr, "convgemm: null args");
   const asw_convgemm_args& a = *args;
@@ -514,6 +738,10 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
   if (a.ln_gamma) {
     ASW_CHECK_ARG(a.ln_beta != nullptr, "convgemm: LayerNorm needs beta");
     ASW_CHECK_ARG(!stats, "convgemm: LayerNorm + stats epilogue is not a reference layer");
+    {
+      const int rc = try_resconv(a, s);
+      if (rc != 1) return rc;
+    }
     switch (a.N) {
       case 64: return launch_prec<256, 64, 32, 4, 1, true, false>(a, s);
       case 128: return launch_prec<128, 128, 32, 2, 2, true, false>(a, s);

@@ -45,8 +45,15 @@ struct WBuf {
   WBuf() = default;
   WBuf(const WBuf&) = delete;
   WBuf& operator=(const WBuf&) = delete;
-  WBuf(WBuf&& o) noexcept : f32(std::move(o.f32)), hi(o.hi), lo(o.lo), shift(o.shift) { o.hi = o.lo = nullptr; }
-  ~WBuf() { if (hi) (void)hipFree(hi); if (lo) (void)hipFree(lo); }
+  WBuf(WBuf&& o) noexcept : f32(std::move(o.f32)), hi(o.hi), lo(o.lo), shift(o.shift), fhi(o.fhi), flo(o.flo) {
+    o.hi = o.lo = o.fhi = o.flo = nullptr;
+  }
+  ~WBuf() {
+    if (hi) (void)hipFree(hi);
+    if (lo) (void)hipFree(lo);
+    if (fhi) (void)hipFree(fhi);
+    if (flo) (void)hipFree(flo);
+  }
   int upload(const std::vector<float>& h) {
     int rc = f32.upload(h);
     if (rc) return rc;
@@ -60,8 +67,24 @@ struct WBuf {
     ASW_HIP(hipMemcpy(lo, vl.data(), h.size() * 2, hipMemcpyHostToDevice));
     return ASW_OK;
   }
+  // fragment-major copy for the halo-staged residual conv (Wt is [N][K])
+  uint16_t* fhi = nullptr;
+  uint16_t* flo = nullptr;
+  int upload_frags(const std::vector<float>& h, int N, int K) {
+    std::vector<uint16_t> vh(h.size()), vl(h.size());
+    int32_t sh = 0;
+    int rc = asw_pack_fragments_f16(h.data(), N, K, vh.data(), vl.data(), &sh);
+    if (rc) return rc;
+    if (sh != shift) return asw::set_error(ASW_ERR_STATE, "fragment pack: inconsistent weight shift");
+    if (hipMalloc(&fhi, h.size() * 2) != hipSuccess || hipMalloc(&flo, h.size() * 2) != hipSuccess)
+      return asw::set_error(ASW_ERR_NOMEM, "hipMalloc(%zu halves)", h.size());
+    ASW_HIP(hipMemcpy(fhi, vh.data(), h.size() * 2, hipMemcpyHostToDevice));
+    ASW_HIP(hipMemcpy(flo, vl.data(), h.size() * 2, hipMemcpyHostToDevice));
+    return ASW_OK;
+  }
   void bind(asw_convgemm_args& a, int precision) const {
     a.Wt = f32.p; a.Wt_hi = hi; a.Wt_lo = lo; a.w_shift = shift; a.precision = precision;
+    a.Wf_hi = fhi; a.Wf_lo = flo;
   }
 };
 
@@ -193,7 +216,13 @@ int pack_res(asw_spot* m, const std::string& p, int ch, std::vector<ResLayer>& o
   for (int j = 0; j < c.residual_layers; ++j) {
     const std::string q = p + ".res.seq." + std::to_string(j);
     int rc;
-    if ((rc = out[j].wt.upload(pack_conv(P(m, q + ".conv.weight"), ch, ch, c.kernel_size, nullptr)))) return rc;
+    {
+      const std::vector<float> packed = pack_conv(P(m, q + ".conv.weight"), ch, ch, c.kernel_size, nullptr);
+      if ((rc = out[j].wt.upload(packed))) return rc;
+      if (ch % 32 == 0 && (ch * c.kernel_size) % 16 == 0 &&
+          (rc = out[j].wt.upload_frags(packed, ch, ch * c.kernel_size)))
+        return rc;
+    }
     if ((rc = out[j].bias.upload(P(m, q + ".conv.bias")))) return rc;
     if ((rc = out[j].g.upload(P(m, q + ".norm.weight")))) return rc;
     if ((rc = out[j].b.upload(P(m, q + ".norm.bias")))) return rc;

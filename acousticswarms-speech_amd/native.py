@@ -63,7 +63,7 @@ class ConvGemmArgs(Structure):
                 ("stride", c_int32), ("dil", c_int32), ("pad", c_int32), ("a_row_stride", c_int32),
                 ("a_batch_stride", c_int64), ("a_len", c_int64), ("chan_mod", c_int32), ("relu", c_int32),
                 ("ln_eps", c_float), ("precision", c_int32), ("w_shift", c_int32), ("Wt_hi", c_void_p),
-                ("Wt_lo", c_void_p)]
+                ("Wt_lo", c_void_p), ("Wf_hi", c_void_p), ("Wf_lo", c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/asw_hip.h
@@ -79,6 +79,7 @@ SIGNATURES = {
     "asw_spot_set_batch": (c_int, [c_void_p, c_int]),
     "asw_spot_set_precision": (c_int, [c_void_p, c_int]),
     "asw_split_weights_f16": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_int32)]),
+    "asw_pack_fragments_f16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_int32)]),
     "asw_spot_shift_and_sep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_int, c_void_p]),
     "asw_spot_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p, c_void_p]),

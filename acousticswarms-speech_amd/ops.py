@@ -25,7 +25,7 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, relu=False, resid=None, mul=None,
              ln=None, stats_chan_mod=0, A2=None, B=None, a_row_stride=None, a_batch_stride=None, a_len=None,
-             out=None, ln_eps=1e-5, precision="f32"):
+             out=None, ln_eps=1e-5, precision="f32", use_fragments=True):
     """out[b][r][n] per include/asw_hip.h:asw_convgemm_f32.  Returns (out, stats|None)."""
     _f32(A); _f32(Wt)
     if B is None:
@@ -58,9 +58,28 @@ def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, re
         hi, lo, shift = split_weights_f16(Wt)
         keep = (hi, lo)
         a.precision, a.w_shift, a.Wt_hi, a.Wt_lo = 1, shift, hi.data_ptr(), lo.data_ptr()
+        if use_fragments and N % 32 == 0 and (taps * Cin) % 16 == 0:
+            fh, fl, sh2 = pack_fragments_f16(Wt, N, taps * Cin)
+            assert sh2 == shift
+            keep = keep + (fh, fl)
+            a.Wf_hi, a.Wf_lo = fh.data_ptr(), fl.data_ptr()
     check(lib().asw_convgemm_f32(byref(a), current_stream()))
     torch.cuda.current_stream().synchronize() if keep is not None else None
     return out, stats
+
+
+def pack_fragments_f16(Wt, N, K):
+    """fp32 device Wt[N][K] -> fragment-major (hi, lo) device tensors + shift (asw_pack_fragments_f16)."""
+    import ctypes
+    import numpy as np
+    w = np.ascontiguousarray(Wt.detach().cpu().numpy(), dtype=np.float32).reshape(N, K)
+    hi = np.empty(w.size, dtype=np.uint16)
+    lo = np.empty(w.size, dtype=np.uint16)
+    sh = ctypes.c_int32()
+    check(lib().asw_pack_fragments_f16(ctypes.c_void_p(w.ctypes.data), N, K, ctypes.c_void_p(hi.ctypes.data),
+                                       ctypes.c_void_p(lo.ctypes.data), byref(sh)))
+    dev = Wt.device
+    return (torch.from_numpy(hi.view(np.int16)).to(dev), torch.from_numpy(lo.view(np.int16)).to(dev), sh.value)
 
 
 def split_weights_f16(Wt):

@@ -172,7 +172,20 @@ typedef struct asw_convgemm_args {
   int32_t w_shift;
   const void* Wt_hi;
   const void* Wt_lo;
+  /* Optional (precision 1): the same split weights in MFMA-fragment order (see
+   * asw_pack_fragments_f16).  When given and the layer is a stride-1 "same" convolution
+   * with C_in == N <= 512, a residual that is the input itself and a LayerNorm epilogue
+   * (the reference's DilatedResidualLayer), the halo-staged kernel is used: each input row
+   * is fetched and split once per workgroup instead of once per tap. */
+  const void* Wf_hi;
+  const void* Wf_lo;
 } asw_convgemm_args;
+/* Host helper: fp32 Wt[N][K] -> fragment-major fp16 hi/lo [K/16][N/32][64 lanes][8]:
+ * lane l of fragment (ks, nt) holds Wt[nt*32 + (l&31)][ks*16 + 8*(l>>5) + j], j < 8, i.e.
+ * exactly the B operand of v_mfma_f32_32x32x16_f16, so a wave fetches a fragment with one
+ * coalesced 1 KiB load.  Pre-scaled by 2^w_shift like asw_split_weights_f16.  N % 32 == 0,
+ * K % 16 == 0; hi/lo: N*K uint16 each (host). */
+int asw_pack_fragments_f16(const float* Wt, int N, int K, uint16_t* hi, uint16_t* lo, int32_t* w_shift);
 int asw_convgemm_f32(const asw_convgemm_args* args, void* stream);
 /* Host helper: split n fp32 weights into the fp16 hi/lo pair used by precision 1 with the
  * power-of-two pre-scale that keeps the lo parts out of the fp16 subnormal range; returns

@@ -37,19 +37,23 @@ def snr_db(got, ref):
     return 10 * np.log10(np.sum(ref ** 2) / max(np.sum((got - ref) ** 2), 1e-300))
 
 
-@pytest.mark.parametrize("C,T,dil", [(64, 1000, 1), (64, 900, 49), (128, 520, 7), (256, 300, 49), (512, 130, 7)])
-def test_residual_layer_f16x3(C, T, dil):
+@pytest.mark.parametrize("frag", [True, False])
+@pytest.mark.parametrize("C,T,dil", [(64, 1000, 1), (64, 900, 49), (64, 100, 49), (64, 777, 7), (128, 520, 7),
+                                     (128, 300, 1), (256, 300, 49), (512, 130, 7), (512, 200, 49)])
+def test_residual_layer_f16x3(C, T, dil, frag):
+    """frag=True goes through the halo-staged kernel (resconv16), frag=False through the
+    generic chunked kernel (convgemm16)."""
     from acousticswarms_speech_amd import ops
-    B, K = 2, 7
+    B, K = 3, 7
     x = _rand(B, C, T, seed=3)
     w = _rand(C, C, K, seed=4, scale=1.0 / math.sqrt(C * K))
     b, g, be = _rand(C, seed=5, scale=0.1), 1 + _rand(C, seed=6, scale=0.1), _rand(C, seed=7, scale=0.1)
     want = F.layer_norm((F.relu(F.conv1d(x, w, b, dilation=dil, padding=3 * dil)) + x).transpose(1, 2), (C,), g, be)
     xc = x.transpose(1, 2).contiguous().cuda()
     out, _ = ops.convgemm(xc, ops.pack_conv_weight(w).cuda(), T, C, C, taps=K, dil=dil, pad=3 * dil, bias=b.cuda(),
-                          relu=True, resid=xc, ln=(g.cuda(), be.cuda()), precision="f16x3")
+                          relu=True, resid=xc, ln=(g.cuda(), be.cuda()), precision="f16x3", use_fragments=frag)
     r = _rel(out.cpu(), want)
-    _log(f"f16x3 res C={C} dil={dil}: rel={r:.3e}")
+    _log(f"f16x3 res C={C} T={T} dil={dil} frag={frag}: rel={r:.3e}")
     assert r < 2e-5
 
 
