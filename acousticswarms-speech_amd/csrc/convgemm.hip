@@ -53,7 +53,7 @@ struct RowsContig {
   __device__ __forceinline__ int operator()(int trow) const { const int t = m0 + trow; return t < M ? t : -1; }
 };
 
-template <int BM, int BN, int WM, int WN, bool LN, bool STATS, typename RowMap>
+template <int BM, int BN, int WM, int WN, bool LN, bool STATS, bool RESID, bool MUL, typename RowMap>
 __device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
                                          float* smem, float acc_scale, const RowMap& rowmap) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -100,22 +100,26 @@ __device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN /
         const int trow = (sr >> 5) * (BM / WM) + tm * 32 + (sr & 31);
         const int t_out = rowmap(trow);
         ok[u] = t_out >= 0;
-        obase[u] = ((long)b * p.M_out + t_out) * p.N + n0;
+        // rows past the end read row 0 (always valid) and are simply not stored: the loads
+        // stay unconditional, so the compiler issues the whole batch before the first wait
+        obase[u] = ((long)b * p.M_out + (ok[u] ? t_out : 0)) * p.N + n0;
 #pragma unroll
         for (int q = 0; q < VPL; ++q) {
           const int col = (lc + q * LPR) * 4;
-          float4 x = *reinterpret_cast<const float4*>(Ct + sr * LDC + col);
-          if (ok[u]) {
-            if (p.resid) {
-              const float4 r = *reinterpret_cast<const float4*>(p.resid + obase[u] + col);
-              x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
-            }
-            if (p.mul) {
-              const float4 g = *reinterpret_cast<const float4*>(p.mul + obase[u] + col);
-              x.x *= g.x; x.y *= g.y; x.z *= g.z; x.w *= g.w;
-            }
-          }
-          v[u][q] = x;
+          if (RESID) v[u][q] = *reinterpret_cast<const float4*>(p.resid + obase[u] + col);
+          if (MUL) v[u][q] = *reinterpret_cast<const float4*>(p.mul + obase[u] + col);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int sr = ((it0 + u) * 4 + wid) * RPI + sub;
+#pragma unroll
+        for (int q = 0; q < VPL; ++q) {
+          const int col = (lc + q * LPR) * 4;
+          const float4 x = *reinterpret_cast<const float4*>(Ct + sr * LDC + col);
+          if (RESID) { v[u][q].x += x.x; v[u][q].y += x.y; v[u][q].z += x.z; v[u][q].w += x.w; }
+          else if (MUL) { v[u][q].x *= x.x; v[u][q].y *= x.y; v[u][q].z *= x.z; v[u][q].w *= x.w; }
+          else v[u][q] = x;
         }
       }
 #pragma unroll
@@ -190,7 +194,7 @@ __device__ __forceinline__ long a_elem(const asw_convgemm_args& p, int idx, int 
 }
 
 // ------------------------------------------------------------------ exact fp32 MFMA
-template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS>
+template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL, bool A2F>
 __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int LDK = BK + 4;
@@ -213,28 +217,28 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p
 
   float4 ra[A_VEC], rb[B_VEC];
 
+  // Loads are unconditional (padding reads element 0 and is zeroed by a select afterwards) and
+  // the skip-connection operand is a compile-time variant: a runtime "load or zero" branch
+  // makes hipcc wait vmcnt(0) after every load, serialising the whole staging phase.
   auto gload = [&](int kc) {
 #pragma unroll
     for (int v = 0; v < A_VEC; ++v) {
       const long e = a_elem<BM, BK>(p, tid + v * 256, kc, cpb, m0);
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e >= 0) {
-        x = *reinterpret_cast<const float4*>(Ab + e);
-        if (A2b) {
-          const float4 y = *reinterpret_cast<const float4*>(A2b + e);
-          x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-        }
+      const long ec = e >= 0 ? e : 0;
+      float4 x = *reinterpret_cast<const float4*>(Ab + ec);
+      if (A2F) {
+        const float4 y = *reinterpret_cast<const float4*>(A2b + ec);
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
       }
-      ra[v] = x;
+      ra[v] = e >= 0 ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int v = 0; v < B_VEC; ++v) {
       const int idx = tid + v * 256;
       const int row = idx / KV, cv = idx - row * KV;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < BN * KV && n0 + row < p.N)
-        x = *reinterpret_cast<const float4*>(p.Wt + (long)(n0 + row) * K + (long)kc * BK + cv * 4);
-      rb[v] = x;
+      const bool ok = idx < BN * KV;
+      const float4 x = *reinterpret_cast<const float4*>(p.Wt + (long)(n0 + (ok ? row : 0)) * K + (long)kc * BK + cv * 4);
+      rb[v] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto lstore = [&]() {
@@ -290,22 +294,27 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p
       }
     }
   }
-  epilogue<BM, BN, WM, WN, LN, STATS>(acc, p, smem, 1.0f, RowsContig{m0, p.M_out});
+  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, 1.0f, RowsContig{m0, p.M_out});
 }
 
 // ------------------------------------------------------------------ f16x3 split MFMA
+// x -> hi + lo with two packed round-toward-zero conversions per pair (v_cvt_pkrtz_f16_f32:
+// finite overflow saturates at +-65504 instead of becoming inf).  hi carries 11 bits, the
+// remainder x - hi is exact in fp32, lo carries its next 11 bits truncated: |x - hi - lo| < 2^-20 |x|.
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const float4 x, half4& hi, half4& lo) {
-  const float v[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float c = fminf(fmaxf(v[i], -65504.f), 65504.f);
-    const _Float16 h = (_Float16)c;
-    hi[i] = h;
-    lo[i] = (_Float16)(c - (float)h);
-  }
+  const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(x.x, x.y);
+  const fp16x2 h23 = __builtin_amdgcn_cvt_pkrtz(x.z, x.w);
+  const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz(x.x - (float)h01[0], x.y - (float)h01[1]);
+  const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz(x.z - (float)h23[0], x.w - (float)h23[1]);
+  union { fp16x2 v[2]; half4 h; } uh, ul;
+  uh.v[0] = h01; uh.v[1] = h23;
+  ul.v[0] = l01; ul.v[1] = l23;
+  hi = uh.h;
+  lo = ul.h;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS>
+template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL, bool A2F>
 __global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(BK % 16 == 0, "k-step of the f16 MFMA");
@@ -332,40 +341,55 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args
   const _Float16* __restrict__ Wh = reinterpret_cast<const _Float16*>(p.Wt_hi);
   const _Float16* __restrict__ Wl = reinterpret_cast<const _Float16*>(p.Wt_lo);
 
-  float4 ra[A_VEC];
-  half8 rbh[B_VEC], rbl[B_VEC];
+  // One staging register set (a second set, i.e. loads two chunks ahead, was measured: no
+  // gain, and its 64 extra VGPRs cost a resident workgroup per CU).
+  float4 ra0[A_VEC];
+  half8 rbh0[B_VEC], rbl0[B_VEC];
 
-  auto gload = [&](int kc) {
+  // per-thread invariants of the staging addresses
+  long a_row[A_VEC];                         // element offset of (row, tap 0, c 0) + this thread's column
+  bool a_ok[A_VEC];
+  long b_row[B_VEC];
+  bool b_ok[B_VEC];
+#pragma unroll
+  for (int v = 0; v < A_VEC; ++v) {
+    const int idx = tid + v * 256;
+    const int row = idx / KV, cv = idx - row * KV;
+    a_row[v] = ((long)(m0 + row) * p.stride - p.pad) * p.a_row_stride + cv * 4;
+    a_ok[v] = (idx < BM * KV) && (m0 + row < p.M_out);
+  }
+#pragma unroll
+  for (int v = 0; v < B_VEC; ++v) {
+    const int idx = tid + v * 256;
+    const int row = idx / KH, cv = idx - row * KH;
+    b_row[v] = (long)(n0 + row) * K + cv * 8;
+    b_ok[v] = (idx < BN * KH) && (n0 + row < p.N);
+  }
+  const long tap_step = (long)p.dil * p.a_row_stride;
+
+  auto gload = [&](int kc, float4 (&ra)[A_VEC], half8 (&rbh)[B_VEC], half8 (&rbl)[B_VEC]) {
+    const int tap = kc / cpb;
+    const long koff = tap * tap_step + (kc - tap * cpb) * BK;
 #pragma unroll
     for (int v = 0; v < A_VEC; ++v) {
-      const long e = a_elem<BM, BK>(p, tid + v * 256, kc, cpb, m0);
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e >= 0) {
-        x = *reinterpret_cast<const float4*>(Ab + e);
-        if (A2b) {
-          const float4 y = *reinterpret_cast<const float4*>(A2b + e);
-          x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-        }
+      const long e = a_row[v] + koff;
+      const bool ok = a_ok[v] && e >= 0 && e + 3 < p.a_len;
+      const long ec = ok ? e : 0;                       // unconditional load + select: see the f32 kernel
+      float4 x = *reinterpret_cast<const float4*>(Ab + ec);
+      if (A2F) {
+        const float4 y = *reinterpret_cast<const float4*>(A2b + ec);
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
       }
-      ra[v] = x;
+      ra[v] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int v = 0; v < B_VEC; ++v) {
-      const int idx = tid + v * 256;
-      const int row = idx / KH, cv = idx - row * KH;
-      half8 h, l;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { h[i] = (_Float16)0.f; l[i] = (_Float16)0.f; }
-      if (idx < BN * KH && n0 + row < p.N) {
-        const long o = (long)(n0 + row) * K + (long)kc * BK + cv * 8;
-        h = *reinterpret_cast<const half8*>(Wh + o);
-        l = *reinterpret_cast<const half8*>(Wl + o);
-      }
-      rbh[v] = h;
-      rbl[v] = l;
+      const long o = (b_ok[v] ? b_row[v] : 0) + (long)kc * BK;
+      rbh[v] = *reinterpret_cast<const half8*>(Wh + o);   // rows past BN*KH are never stored to LDS
+      rbl[v] = *reinterpret_cast<const half8*>(Wl + o);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](const float4 (&ra)[A_VEC], const half8 (&rbh)[B_VEC], const half8 (&rbl)[B_VEC]) {
 #pragma unroll
     for (int v = 0; v < A_VEC; ++v) {
       const int idx = tid + v * 256;
@@ -399,12 +423,7 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args
   const int a_off = (wm * (BM / WM) + (lane & 31)) * LDH + (lane >> 5) * 8;
   const int b_off = (wn * (BN / WN) + (lane & 31)) * LDH + (lane >> 5) * 8;
 
-  gload(0);
-  for (int kc = 0; kc < nk; ++kc) {
-    __syncthreads();
-    lstore();
-    __syncthreads();
-    if (kc + 1 < nk) gload(kc + 1);
+  auto compute = [&]() {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       half8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -427,8 +446,17 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
+  };
+
+  gload(0, ra0, rbh0, rbl0);
+  for (int kc = 0; kc < nk; ++kc) {
+    __syncthreads();
+    lstore(ra0, rbh0, rbl0);
+    __syncthreads();
+    if (kc + 1 < nk) gload(kc + 1, ra0, rbh0, rbl0);
+    compute();
   }
-  epilogue<BM, BN, WM, WN, LN, STATS>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out});
+  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out});
 }
 
 // ------------------------------------------------------------------ halo-staged residual conv
@@ -524,9 +552,9 @@ __global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args 
           g = dil * (jb * BMJ + row % RJ - (taps - 1) / 2) + ph;
           ok = ok && ph < dil && (jb * BMJ + row % RJ - (taps - 1) / 2) >= 0;
         }
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && g >= 0 && g < T) x = *reinterpret_cast<const float4*>(xb + (long)g * C + cc * 64 + sc4 * 4);
-        buf[u] = x;
+        ok = ok && g >= 0 && g < T;
+        const float4 x = *reinterpret_cast<const float4*>(xb + (long)(ok ? g : 0) * C + cc * 64 + sc4 * 4);
+        buf[u] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -541,7 +569,6 @@ __global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args 
     }
     __syncthreads();
     // ---- taps x k-steps, B fragments double-buffered in registers
-    half8 bh0[TN], bl0[TN], bh1[TN], bl1[TN];
     auto bload = [&](int tap, int ks, half8 (&bh)[TN], half8 (&bl)[TN]) {
       const long kg = (long)tap * (C / 16) + cc * 4 + ks;          // global k-step
 #pragma unroll
@@ -568,19 +595,22 @@ __global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
-    bload(0, 0, bh0, bl0);
+    // One register buffer per k-step of a tap: the fragment for (tap+1, ks) is requested
+    // right after (tap, ks) has been multiplied, i.e. three k-steps (600-1200 MFMA cycles)
+    // before its use -- enough to cover an L2 hit without the register cost of a second
+    // whole-tap set (which halves occupancy; measured slower for C <= 128).
+    half8 qh[4][TN], ql[4][TN];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bload(0, ks, qh[ks], ql[ks]);
     for (int tap = 0; tap < taps; ++tap) {
-      bload(tap, 1, bh1, bl1);
-      compute(tap, 0, bh0, bl0);
-      bload(tap, 2, bh0, bl0);
-      compute(tap, 1, bh1, bl1);
-      bload(tap, 3, bh1, bl1);
-      compute(tap, 2, bh0, bl0);
-      if (tap + 1 < taps) bload(tap + 1, 0, bh0, bl0);
-      compute(tap, 3, bh1, bl1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        compute(tap, ks, qh[ks], ql[ks]);
+        if (tap + 1 < taps) bload(tap + 1, ks, qh[ks], ql[ks]);
+      }
     }
   }
-  epilogue<BM, C, WM, WN, true, false>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
+  epilogue<BM, C, WM, WN, true, false, true, false>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
                                        ResRows<BM, PH>{m0, jb, pb, dil, T});
 }
 
@@ -627,37 +657,39 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool F16>
+template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL, bool F16, bool A2F = false>
 int launch(const asw_convgemm_args& a, hipStream_t s) {
   constexpr size_t stage = F16 ? (size_t)(BM + BN) * (BK + 8) * 2 * sizeof(_Float16)
                                : (size_t)(BM + BN) * (BK + 4) * sizeof(float);
   constexpr size_t slab = (size_t)(WM * 32) * (BN + 4) * sizeof(float);
   constexpr size_t smem = stage > slab ? stage : slab;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  const void* kern = F16 ? reinterpret_cast<const void*>(convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS>)
-                         : reinterpret_cast<const void*>(convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS>);
+  const void* kern = F16 ? reinterpret_cast<const void*>(convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>)
+                         : reinterpret_cast<const void*>(convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>);
   static bool attr_set = false;
   if (!attr_set) {
     ASW_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
+  ASW_CHECK_ARG(A2F == (a.A2 != nullptr), "convgemm: the skip operand is fused only in the 128-wide statistics tile");
   ASW_CHECK_ARG(a.Cin % BK == 0, "convgemm: Cin=%d not a multiple of BK=%d", a.Cin, BK);
   ASW_CHECK_ARG(a.N % BN == 0, "convgemm: N=%d not a multiple of BN=%d", a.N, BN);
   dim3 grid(asw::cdiv(a.M_out, BM), a.N / BN, a.B);
-  asw::ProfScope prof(s, asw::prof_name(F16 ? "convgemm16" : "convgemm", BM, BN, BK, LN, STATS),
+  asw::ProfScope prof(s, asw::prof_name(F16 ? (MUL ? "convgemm16m" : "convgemm16") : (MUL ? "convgemm_m" : "convgemm"),
+                                        BM, BN, BK, LN, STATS),
                       2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
   if (F16)
-    hipLaunchKernelGGL((convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>), grid, dim3(256), smem, s, a);
   else
-    hipLaunchKernelGGL((convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>), grid, dim3(256), smem, s, a);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS>
+template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL = false>
 int launch_prec(const asw_convgemm_args& a, hipStream_t s) {
-  return a.precision == 1 ? launch<BM, BN, BK, WM, WN, LN, STATS, true>(a, s)
-                          : launch<BM, BN, BK, WM, WN, LN, STATS, false>(a, s);
+  return a.precision == 1 ? launch<BM, BN, BK, WM, WN, LN, STATS, MUL, true>(a, s)
+                          : launch<BM, BN, BK, WM, WN, LN, STATS, MUL, false>(a, s);
 }
 
 // tile choice for the non-LayerNorm variants; must match asw_convgemm_stats_tiles
@@ -735,8 +767,11 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
   ASW_CHECK_ARG(a.B <= 65535, "convgemm: batch %d exceeds grid.z", a.B);
   const bool stats = a.stats != nullptr;
   if (stats) ASW_CHECK_ARG(a.chan_mod >= 2 && a.chan_mod % 2 == 0, "convgemm: stats need even chan_mod");
+  ASW_CHECK_ARG(!(a.resid && !a.ln_gamma), "convgemm: a residual is fused only together with LayerNorm");
+  ASW_CHECK_ARG(!(a.mul && (a.ln_gamma || stats || !wide_tile(a.N))),
+                "convgemm: the gate tensor is fused only in the plain 128-wide tile");
   if (a.ln_gamma) {
-    ASW_CHECK_ARG(a.ln_beta != nullptr, "convgemm: LayerNorm needs beta");
+    ASW_CHECK_ARG(a.ln_beta != nullptr && a.resid != nullptr, "convgemm: LayerNorm needs beta and a residual");
     ASW_CHECK_ARG(!stats, "convgemm: LayerNorm + stats epilogue is not a reference layer");
     {
       const int rc = try_resconv(a, s);
@@ -753,6 +788,10 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
     }
   }
   if (wide_tile(a.N)) {
+    if (a.mul) return launch_prec<128, 128, 32, 2, 2, false, false, true>(a, s);
+    if (stats && a.A2)
+      return a.precision == 1 ? launch<128, 128, 32, 2, 2, false, true, false, true, true>(a, s)
+                              : launch<128, 128, 32, 2, 2, false, true, false, false, true>(a, s);
     return stats ? launch_prec<128, 128, 32, 2, 2, false, true>(a, s) : launch_prec<128, 128, 32, 2, 2, false, false>(a, s);
   }
   ASW_CHECK_ARG(a.N % 64 == 0, "convgemm: N=%d must be a multiple of 64", a.N);
