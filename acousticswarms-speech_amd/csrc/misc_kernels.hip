@@ -314,9 +314,16 @@ extern "C" int asw_gn_glu(const float* raw, const float* stats, int n_partials, 
   return ASW_OK;
 }
 
+namespace asw { int attention_mfma(const float* qkv, int B, int L, int d, int nhead, float* ctx, hipStream_t s); }
+
 extern "C" int asw_attention(const float* qkv, int B, int L, int d, int nhead, float* ctx, void* stream) {
   ASW_CHECK_ARG(qkv && ctx, "attention: null pointer");
   ASW_CHECK_ARG(B > 0 && L > 0 && nhead > 0 && d % nhead == 0, "attention: bad shape");
+  ASW_CHECK_ARG(B <= 65535 && nhead <= 65535, "attention: grid too large");
+  {
+    const int rc = asw::attention_mfma(qkv, B, L, d, nhead, ctx, asw::as_stream(stream));   // L <= 192, hd 128
+    if (rc != 1) return rc;
+  }
   const int hd = d / nhead;
   ASW_CHECK_ARG(hd % 16 == 0 && hd <= 16 * ATT_MAXD, "attention: head_dim %d must be a multiple of 16, <= 128", hd);
   ASW_CHECK_ARG(B <= 65535 && nhead <= 65535, "attention: grid too large");

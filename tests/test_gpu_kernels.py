@@ -162,7 +162,8 @@ def test_linear_residual_layernorm(ops, d, f, L, B):
     assert rel < 2e-6
 
 
-@pytest.mark.parametrize("L,d,nhead,B", [(19, 128, 8, 3), (188, 1024, 8, 2), (300, 1024, 8, 1)])
+@pytest.mark.parametrize("L,d,nhead,B", [(19, 128, 8, 3), (188, 1024, 8, 2), (300, 1024, 8, 1), (150, 1024, 8, 2),
+                                         (192, 1024, 8, 1), (33, 1024, 8, 2), (47, 512, 4, 2)])
 def test_attention(ops, L, d, nhead, B):
     qkv = _rand(B, L, 3 * d, seed=28)
     hd = d // nhead
