@@ -54,7 +54,8 @@ struct RowsContig {
 };
 
 template <int BM, int BN, int WM, int WN, bool LN, bool STATS, bool RESID, bool MUL, typename RowMap>
-__device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
+__device__ __forceinline__ void epilogue(  // WM*WN waves (4 or 8)
+floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
                                          float* smem, float acc_scale, const RowMap& rowmap) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDC = BN + 4;
@@ -84,19 +85,22 @@ __device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN /
     // instruction, VPL float4 per lane), so each wave walks its 8*WM slab rows in 8 steps.
     // Steps are processed four at a time with every global load (residual / gate tensor)
     // issued before the first use: the loads of four steps overlap instead of serialising.
+    constexpr int NW = WM * WN;
     constexpr int LPR = (BN / 4 < 64) ? BN / 4 : 64;
     constexpr int RPI = 64 / LPR;
     constexpr int VPL = BN / 4 / LPR;
-    constexpr int UNR = 4;
+    constexpr int NSTEP = WM * 32 / (NW * RPI);        // steps each wave needs for its slab rows
+    constexpr int UNR = NSTEP < 4 ? NSTEP : 4;
+    static_assert(NSTEP >= 1 && NSTEP % UNR == 0 && WM * 32 == NSTEP * NW * RPI, "slab rows must split evenly");
     const int sub = lane / LPR, lc = lane % LPR;
 #pragma unroll
-    for (int it0 = 0; it0 < 8; it0 += UNR) {
+    for (int it0 = 0; it0 < NSTEP; it0 += UNR) {
       float4 v[UNR][VPL];
       long obase[UNR];
       bool ok[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int sr = ((it0 + u) * 4 + wid) * RPI + sub;
+        const int sr = ((it0 + u) * NW + wid) * RPI + sub;
         const int trow = (sr >> 5) * (BM / WM) + tm * 32 + (sr & 31);
         const int t_out = rowmap(trow);
         ok[u] = t_out >= 0;
@@ -112,7 +116,7 @@ __device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN /
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int sr = ((it0 + u) * 4 + wid) * RPI + sub;
+        const int sr = ((it0 + u) * NW + wid) * RPI + sub;
 #pragma unroll
         for (int q = 0; q < VPL; ++q) {
           const int col = (lc + q * LPR) * 4;
@@ -173,8 +177,12 @@ __device__ __forceinline__ void epilogue(floatx16 (&acc)[BM / WM / 32][BN / WN /
     if (lane == 0) { red[wid * 4 + 0] = st0; red[wid * 4 + 1] = sq0; red[wid * 4 + 2] = st1; red[wid * 4 + 3] = sq1; }
     __syncthreads();
     if (tid < 4) {
-      const float s = red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
-      const long part = ((long)b * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM * WN; ++w) s += red[w * 4 + tid];
+      // slot layout is independent of the tile shape: stats_stride slots per batch item (the
+      // launcher zero-fills the buffer, smaller grids simply leave slots at zero)
+      const long part = (long)b * p.stats_stride + (long)blockIdx.x * gridDim.y + blockIdx.y;
       p.stats[part * 4 + tid] = s;
     }
   }
@@ -315,14 +323,15 @@ __device__ __forceinline__ void split4(const float4 x, half4& hi, half4& lo) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL, bool A2F>
-__global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args p) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(64 * WM * WN) void convgemm16_kernel(const asw_convgemm_args p) {
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   static_assert(BK % 16 == 0, "k-step of the f16 MFMA");
+  constexpr int NT = 64 * WM * WN;           // threads
   constexpr int LDH = BK + 8;                // halves per staged row
   constexpr int KV = BK / 4;                 // float4 (A, fp32) per row
   constexpr int KH = BK / 8;                 // 16-byte vectors (B, fp16) per row
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_VEC = (BM * KV + 255) / 256, B_VEC = (BN * KH + 255) / 256;
+  constexpr int A_VEC = (BM * KV + NT - 1) / NT, B_VEC = (BN * KH + NT - 1) / NT;
 
   extern __shared__ __align__(16) float smem[];
   _Float16* Ah = reinterpret_cast<_Float16*>(smem);
@@ -353,14 +362,14 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args
   bool b_ok[B_VEC];
 #pragma unroll
   for (int v = 0; v < A_VEC; ++v) {
-    const int idx = tid + v * 256;
+    const int idx = tid + v * NT;
     const int row = idx / KV, cv = idx - row * KV;
     a_row[v] = ((long)(m0 + row) * p.stride - p.pad) * p.a_row_stride + cv * 4;
     a_ok[v] = (idx < BM * KV) && (m0 + row < p.M_out);
   }
 #pragma unroll
   for (int v = 0; v < B_VEC; ++v) {
-    const int idx = tid + v * 256;
+    const int idx = tid + v * NT;
     const int row = idx / KH, cv = idx - row * KH;
     b_row[v] = (long)(n0 + row) * K + cv * 8;
     b_ok[v] = (idx < BN * KH) && (n0 + row < p.N);
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args
   auto lstore = [&](const float4 (&ra)[A_VEC], const half8 (&rbh)[B_VEC], const half8 (&rbl)[B_VEC]) {
 #pragma unroll
     for (int v = 0; v < A_VEC; ++v) {
-      const int idx = tid + v * 256;
+      const int idx = tid + v * NT;
       const int row = idx / KV, cv = idx - row * KV;
       if (idx < BM * KV) {
         half4 hi, lo;
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(const asw_convgemm_args
     }
 #pragma unroll
     for (int v = 0; v < B_VEC; ++v) {
-      const int idx = tid + v * 256;
+      const int idx = tid + v * NT;
       const int row = idx / KH, cv = idx - row * KH;
       if (idx < BN * KH) {
         *reinterpret_cast<half8*>(Bh + row * LDH + cv * 8) = rbh[v];
@@ -664,8 +673,9 @@ int launch(const asw_convgemm_args& a, hipStream_t s) {
   constexpr size_t slab = (size_t)(WM * 32) * (BN + 4) * sizeof(float);
   constexpr size_t smem = stage > slab ? stage : slab;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  const void* kern = F16 ? reinterpret_cast<const void*>(convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>)
-                         : reinterpret_cast<const void*>(convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>);
+  const void* kern;
+  if constexpr (F16) kern = reinterpret_cast<const void*>(convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>);
+  else kern = reinterpret_cast<const void*>(convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>);
   static bool attr_set = false;
   if (!attr_set) {
     ASW_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -678,8 +688,8 @@ int launch(const asw_convgemm_args& a, hipStream_t s) {
   asw::ProfScope prof(s, asw::prof_name(F16 ? (MUL ? "convgemm16m" : "convgemm16") : (MUL ? "convgemm_m" : "convgemm"),
                                         BM, BN, BK, LN, STATS),
                       2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
-  if (F16)
-    hipLaunchKernelGGL((convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>), grid, dim3(256), smem, s, a);
+  if constexpr (F16)
+    hipLaunchKernelGGL((convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>), grid, dim3(64 * WM * WN), smem, s, a);
   else
     hipLaunchKernelGGL((convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>), grid, dim3(256), smem, s, a);
   ASW_LAUNCH_CHECK();
@@ -694,10 +704,20 @@ int launch_prec(const asw_convgemm_args& a, hipStream_t s) {
 
 // tile choice for the non-LayerNorm variants; must match asw_convgemm_stats_tiles
 inline bool wide_tile(int N) { return N % 128 == 0; }
+// f16x3 only: 2 = 256x256 (8 waves), 0 = 128x128.  The big tile halves the bytes pulled per
+// MAC but needs a grid of >= 2 workgroups per CU to stay balanced (measured: mask encoder
+// 242 -> 267 TFLOP/s, deep down/up convs 169 -> 201, but the 288-workgroup QKV GEMM is
+// faster on 128x128).
+inline int wide_tile_kind(int B, int M_out, int N, int K) {
+  if (M_out <= 128 || N % 256 != 0 || K < 256) return 0;
+  const long blocks = (long)asw::cdiv(M_out, 256) * (N / 256) * B;
+  return blocks >= 512 ? 2 : 0;
+}
 
 }  // namespace
 
 extern "C" int asw_convgemm_stats_tiles(int M_out, int N) {
+  // upper bound over the tile choices of both precisions (the smallest tiles)
   if (wide_tile(N)) return asw::cdiv(M_out, 128) * (N / 128);
   return asw::cdiv(M_out, 256) * (N / 64);
 }
@@ -755,8 +775,12 @@ extern "C" int asw_pack_fragments_f16(const float* Wt, int N, int K, uint16_t* h
 
 extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
   ASW_CHECK_ARG(args != nullptr, "convgemm: null args");
-  const asw_convgemm_args& a = *args;
+  asw_convgemm_args a = *args;
   hipStream_t s = asw::as_stream(stream);
+  if (a.stats) {
+    a.stats_stride = asw_convgemm_stats_tiles(a.M_out, a.N);
+    ASW_HIP(hipMemsetAsync(a.stats, 0, (size_t)a.B * a.stats_stride * 4 * sizeof(float), s));
+  }
   ASW_CHECK_ARG(a.A && a.out, "convgemm: null tensor");
   ASW_CHECK_ARG(a.precision == 0 || a.precision == 1, "convgemm: precision %d", a.precision);
   if (a.precision == 1) ASW_CHECK_ARG(a.Wt_hi && a.Wt_lo, "convgemm: f16x3 needs Wt_hi/Wt_lo");
@@ -788,6 +812,23 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
     }
   }
   if (wide_tile(a.N)) {
+    if (a.precision == 1) {
+      // f16x3 is bound by the bytes each CU can pull per cycle, so take the largest tile the
+      // shape fills: 256x256 (8 waves, 1/32 B per MAC), 256x128, else 128x128 (1/16 B per MAC)
+      const int t = wide_tile_kind(a.B, a.M_out, a.N, a.taps * a.Cin);
+      if (t == 2) {
+        if (a.mul) return launch<256, 256, 32, 2, 4, false, false, true, true>(a, s);
+        if (stats && a.A2) return launch<256, 256, 32, 2, 4, false, true, false, true, true>(a, s);
+        return stats ? launch<256, 256, 32, 2, 4, false, true, false, true>(a, s)
+                     : launch<256, 256, 32, 2, 4, false, false, false, true>(a, s);
+      }
+      if (t == 1) {
+        if (a.mul) return launch<256, 128, 32, 4, 2, false, false, true, true>(a, s);
+        if (stats && a.A2) return launch<256, 128, 32, 4, 2, false, true, false, true, true>(a, s);
+        return stats ? launch<256, 128, 32, 4, 2, false, true, false, true>(a, s)
+                     : launch<256, 128, 32, 4, 2, false, false, false, true>(a, s);
+      }
+    }
     if (a.mul) return launch_prec<128, 128, 32, 2, 2, false, false, true>(a, s);
     if (stats && a.A2)
       return a.precision == 1 ? launch<128, 128, 32, 2, 2, false, true, false, true, true>(a, s)

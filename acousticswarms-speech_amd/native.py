@@ -63,7 +63,7 @@ class ConvGemmArgs(Structure):
                 ("stride", c_int32), ("dil", c_int32), ("pad", c_int32), ("a_row_stride", c_int32),
                 ("a_batch_stride", c_int64), ("a_len", c_int64), ("chan_mod", c_int32), ("relu", c_int32),
                 ("ln_eps", c_float), ("precision", c_int32), ("w_shift", c_int32), ("Wt_hi", c_void_p),
-                ("Wt_lo", c_void_p), ("Wf_hi", c_void_p), ("Wf_lo", c_void_p)]
+                ("Wt_lo", c_void_p), ("Wf_hi", c_void_p), ("Wf_lo", c_void_p), ("stats_stride", c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/asw_hip.h

@@ -179,6 +179,7 @@ typedef struct asw_convgemm_args {
    * is fetched and split once per workgroup instead of once per tap. */
   const void* Wf_hi;
   const void* Wf_lo;
+  int32_t stats_stride;   /* set by the library: partial-statistics slots per batch item */
 } asw_convgemm_args;
 /* Host helper: fp32 Wt[N][K] -> fragment-major fp16 hi/lo [K/16][N/32][64 lanes][8]:
  * lane l of fragment (ks, nt) holds Wt[nt*32 + (l&31)][ks*16 + 8*(l>>5) + j], j < 8, i.e.
