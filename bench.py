@@ -52,6 +52,33 @@ def cpu_baseline(cfg, sd, mix, offsets, n_sample):
                       f"oracle.spot_ref.shift_and_sep + energies, {dt:.1f} s"}
 
 
+def e2e_latency(model, scene, dev):
+    """Second half of BASELINE.json's metric: end-to-end localise(+separate) latency of ONE
+    mixture through the whole pipeline (JointModel.forward: SRP-PHAT -> coarse -> fine ->
+    clustering), per stage as JointModel.times (sep/training/JointModel/network.py:143-194),
+    with device synchronisation at every stage boundary; geometry setup() excluded, as the
+    reference's README says.  Seeded random weights: the candidate counts of the search are
+    those a random network produces (close to the worst case of 30 coarse survivors)."""
+    import io
+    from contextlib import redirect_stdout
+    from acousticswarms_speech_amd.joint import JointModel
+    jm = JointModel(model, None, device=dev)
+    mix = torch.from_numpy(scene.mix)
+    with redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        jm.setup(scene.mic_positions, scene.speaker_range)
+        setup_s = time.perf_counter() - t0
+        jm.forward(mix)                                   # warm-up (workspace growth, gate cache)
+        out = jm.forward(mix)
+    mp = jm.Mic_processor
+    return {"unit": "ms", "total": round(sum(jm.times) * 1e3, 2),
+            "stages": {k: round(v * 1e3, 2) for k, v in zip(["srp_phat", "coarse", "fine", "clustering", "joint_sep"],
+                                                            jm.times)},
+            "spot_calls": {"coarse": int(mp.big_spotforming_times), "fine": int(mp.spotforming_times)},
+            "talkers_found": len(out[0]), "setup_excluded_s": round(setup_s, 2),
+            "note": "joint separation network is a next-row component (stage 5 = 0)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,8 +87,9 @@ def main():
     ap.add_argument("--candidates", type=int, default=256, help="candidates per GPU per step")
     ap.add_argument("--samples", type=int, default=48000, help="T: 48000 = 3 s @ 16 kHz (BASELINE literal)")
     ap.add_argument("--batch", type=int, default=64, help="internal candidate batch (spot_batch_size)")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="candidates timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="candidates timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-library per-kernel event timing")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end pipeline latency measurement")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
                     help="GEMM arithmetic: exact f32 MFMA, or f16x3 split-operand MFMA (105 dB SNR vs the reference)")
     args = ap.parse_args()
@@ -163,6 +191,9 @@ def main():
                     "per_kernel": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                                        "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+        e2e = None
+        if not args.no_e2e:
+            e2e = e2e_latency(model, scene, dev)
         cpu = None
         if args.cpu_sample > 0:
             cpu = cpu_baseline(cfg, sd, torch.from_numpy(scene.mix), offsets, args.cpu_sample)
@@ -177,7 +208,7 @@ def main():
                        "candidates_per_gpu_per_step": args.candidates, "internal_batch": args.batch,
                        "gflop_per_candidate": round(fl["total"] / 1e9, 2), "parallelism": f"candidate-shard x{world}"},
             "effective_tflops": round(value * fl["total"] / 1e12, 2),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "e2e_latency": e2e,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
