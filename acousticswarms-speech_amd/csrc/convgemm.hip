@@ -656,7 +656,10 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
                      !a.mul && !a.stats && a.pad * 2 == (a.taps - 1) * a.dil &&
                      a.a_len == (int64_t)a.M_out * a.Cin && a.a_batch_stride == a.a_len;
   if (!shape) return 1;
-  const bool poly = a.dil >= 16;                       // large dilation: polyphase row sets
+  // large dilation: polyphase row sets -- but only while every phase still fills a 32-row
+  // MFMA tile; on short sequences (T/dil < 32, e.g. T = 752 at dil 49) most of each tile
+  // would be empty (measured: 141 vs 243 TFLOP/s), so those stay contiguous
+  const bool poly = a.dil >= 16 && a.M_out / a.dil >= 32;
   switch (a.N) {
     case 64: return poly ? launch_res<128, 64, 4, 1, 4>(a, s) : launch_res<128, 64, 4, 1, 1>(a, s);
     case 128: return poly ? launch_res<128, 128, 2, 2, 4>(a, s) : launch_res<128, 128, 2, 2, 1>(a, s);
