@@ -73,8 +73,10 @@ __global__ __launch_bounds__(1024) void shift_stats_kernel(const float* __restri
   }
 }
 
-// grid (row tiles, N).  Thread = (row within tile, float4 of output channels); a wave
-// writes whole 256-byte channel rows back to back.
+// grid (row tiles, N).  Two phases per 64-row tile: (1) the M aligned, quantised, normalised
+// input samples of every row are computed once into LDS (one (row, mic) pair per thread);
+// (2) thread = (row, float4 of output channels) does only the M fmas per channel from LDS
+// and a wave writes whole 256-byte channel rows back to back.
 template <bool SHIFTED>
 __global__ __launch_bounds__(256) void preproc_kernel(const float* __restrict__ src, int M, int T, int T_pad,
                                                       const int32_t* __restrict__ offsets, int circular,
@@ -83,7 +85,10 @@ __global__ __launch_bounds__(256) void preproc_kernel(const float* __restrict__ 
                                                       int C, float* __restrict__ x0, float* __restrict__ refn,
                                                       long refn_stride, int rows_per_block) {
   __shared__ int off[MAX_MICS];
+  __shared__ float vs[64 * MAX_MICS];       // [row][m], rows_per_block <= 64
+  __shared__ float ws[128 * MAX_MICS];      // preproc weights [C][M], C <= 128
   const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < C * M; i += blockDim.x) ws[i] = w[i];
   const int c4n = C >> 2;                   // float4 groups per row
   if (threadIdx.x < M) {
     int o = 0;
@@ -98,6 +103,24 @@ __global__ __launch_bounds__(256) void preproc_kernel(const float* __restrict__ 
   const float mu = SHIFTED ? mean[n] : 0.f;
   const float sg = SHIFTED ? stdv[n] : 1.f;
   const int row0 = blockIdx.x * rows_per_block;
+  for (int it = threadIdx.x; it < rows_per_block * M; it += blockDim.x) {
+    const int m = it / rows_per_block, r = it - m * rows_per_block;   // consecutive lanes -> consecutive samples
+    const int tp = row0 + r;
+    float x = 0.f;
+    if (tp >= pad && tp < T_pad) {
+      const int t = tp - pad;
+      if (SHIFTED) {
+        int i = t + off[m];
+        if (circular) { if (i >= T) i -= T; x = src[(long)m * T + i]; }
+        else x = (i >= 0 && i < T) ? src[(long)m * T + i] : 0.f;
+        x = (quant16(x) - mu) / sg;
+      } else {
+        x = src[((long)n * M + m) * T + t];
+      }
+    }
+    vs[r * M + m] = x;
+  }
+  __syncthreads();
   const int items = rows_per_block * c4n;
   for (int it = threadIdx.x; it < items; it += blockDim.x) {
     const int r = it / c4n, c4 = it - r * c4n;
@@ -105,28 +128,17 @@ __global__ __launch_bounds__(256) void preproc_kernel(const float* __restrict__ 
     if (tp >= T_pad) break;
     const int c = c4 * 4;
     float4 o = *reinterpret_cast<const float4*>(bias + c);
-    float v0 = 0.f;
     if (tp >= pad) {
-      const int t = tp - pad;
       for (int m = 0; m < M; ++m) {
-        float x;
-        if (SHIFTED) {
-          int i = t + off[m];
-          if (circular) { if (i >= T) i -= T; x = src[(long)m * T + i]; }
-          else x = (i >= 0 && i < T) ? src[(long)m * T + i] : 0.f;
-          x = (quant16(x) - mu) / sg;
-        } else {
-          x = src[((long)n * M + m) * T + t];
-        }
-        if (m == 0) v0 = x;
-        o.x = fmaf(w[(c + 0) * M + m], x, o.x);
-        o.y = fmaf(w[(c + 1) * M + m], x, o.y);
-        o.z = fmaf(w[(c + 2) * M + m], x, o.z);
-        o.w = fmaf(w[(c + 3) * M + m], x, o.w);
+        const float x = vs[r * M + m];
+        o.x = fmaf(ws[(c + 0) * M + m], x, o.x);
+        o.y = fmaf(ws[(c + 1) * M + m], x, o.y);
+        o.z = fmaf(ws[(c + 2) * M + m], x, o.z);
+        o.w = fmaf(ws[(c + 3) * M + m], x, o.w);
       }
     }
     *reinterpret_cast<float4*>(x0 + ((long)n * T_pad + tp) * C + c) = o;
-    if (c4 == 0) refn[(long)n * refn_stride + tp] = v0;
+    if (c4 == 0) refn[(long)n * refn_stride + tp] = vs[r * M];
   }
 }
 
@@ -149,8 +161,8 @@ extern "C" int asw_shift_norm_preproc(const float* mix, int M, int T, int T_pad,
                                       void* stream) {
   ASW_CHECK_ARG(refn_stride >= T_pad, "shift_norm_preproc: refn_stride < T_pad");
   ASW_CHECK_ARG(mix && offsets && mean && std && w && b && x0 && refn, "shift_norm_preproc: null pointer");
-  ASW_CHECK_ARG(M >= 1 && M <= MAX_MICS && T >= 1 && T_pad >= T && C % 4 == 0 && C > 0,
-                "shift_norm_preproc: bad shape M=%d T=%d T_pad=%d C=%d", M, T, T_pad, C);
+  ASW_CHECK_ARG(M >= 1 && M <= MAX_MICS && T >= 1 && T_pad >= T && C % 4 == 0 && C > 0 && C <= 128,
+                "shift_norm_preproc: bad shape M=%d T=%d T_pad=%d C=%d (C <= 128)", M, T, T_pad, C);
   if (N == 0) return ASW_OK;
   const int rows = 64;
   dim3 grid(asw::cdiv(T_pad, rows), N);
@@ -164,8 +176,8 @@ extern "C" int asw_pad_preproc(const float* x, int B, int M, int t, int T_pad, c
                                int C, float* x0, float* refn, long refn_stride, void* stream) {
   ASW_CHECK_ARG(refn_stride >= T_pad, "pad_preproc: refn_stride < T_pad");
   ASW_CHECK_ARG(x && w && b && x0 && refn, "pad_preproc: null pointer");
-  ASW_CHECK_ARG(M >= 1 && M <= MAX_MICS && t >= 1 && T_pad >= t && C % 4 == 0 && C > 0,
-                "pad_preproc: bad shape M=%d t=%d T_pad=%d C=%d", M, t, T_pad, C);
+  ASW_CHECK_ARG(M >= 1 && M <= MAX_MICS && t >= 1 && T_pad >= t && C % 4 == 0 && C > 0 && C <= 128,
+                "pad_preproc: bad shape M=%d t=%d T_pad=%d C=%d (C <= 128)", M, t, T_pad, C);
   if (B == 0) return ASW_OK;
   const int rows = 64;
   dim3 grid(asw::cdiv(T_pad, rows), B);
