@@ -182,8 +182,16 @@ def main():
             ach = rec["work"] / (rec["ms"] * 1e-3) / 1e12
             tot_ms = sum(r["ms"] for r in prof.values())
             tot_work = sum(r["work"] for r in prof.values())
+            traffic = None
+            try:      # measured offline by rocprofv3 --pmc (separate passes); only valid for the same kernel
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
+                if tj["kernel"] == name:
+                    traffic = {"read_bytes_per_launch_raw": tj["read_bytes_raw"], "write_bytes_per_launch": tj["write_bytes"],
+                               "algorithmic_bytes_per_launch": tj["algorithmic_bytes"], "source": "profiles/r1/traffic.json"}
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(rec["ms"] / rec["launches"], 4), "launches": rec["launches"],
                     "all_gemm_kernels": {"achieved": round(tot_work / (tot_ms * 1e-3) / 1e12, 2),
                                          "frac": round(tot_work / (tot_ms * 1e-3) / 1e12 / peak, 4),
