@@ -300,7 +300,31 @@ __global__ __launch_bounds__(256) void pair_sisdr_kernel(const float* __restrict
   }
 }
 
+// x[b][:] -= mean(x[b][:])   (sep/Mic_Array.py:291: the stage loops centre every candidate
+// output before measuring / comparing it); mean accumulated in double, applied as float32
+__global__ __launch_bounds__(1024) void center_rows_kernel(float* __restrict__ y, int T) {
+  __shared__ double red[16];
+  float* yb = y + (long)blockIdx.x * T;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < T; i += 1024) acc += (double)yb[i];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  double tot = 0.0;
+  for (int i = 0; i < 16; ++i) tot += red[i];
+  const float mu = (float)(tot / (double)T);
+  for (int i = threadIdx.x; i < T; i += 1024) yb[i] -= mu;
+}
+
 }  // namespace
+
+extern "C" int asw_center_rows(float* y, int B, int T, void* stream) {
+  ASW_CHECK_ARG(y && T > 0, "center_rows: bad argument");
+  if (B <= 0) return ASW_OK;
+  hipLaunchKernelGGL(center_rows_kernel, dim3(B), dim3(1024), 0, asw::as_stream(stream), y, T);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
 
 extern "C" int asw_gn_glu(const float* raw, const float* stats, int n_partials, const float* gamma,
                           const float* beta, int B, int T, int C, float eps, float* out, void* stream) {

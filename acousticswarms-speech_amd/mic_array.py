@@ -125,7 +125,17 @@ class MicArray(object):
             total_patch.extend(fine)
             bounds.append(self.spotforming_times)
 
-        sep_all = spot_model.shift_and_sep(mix_data, total_patch, Strict=1)      # the hot call
+        # the hot call.  With the HIP spot model the N x T outputs stay on the GPU: energies come
+        # from the device reduction, SI-SDR similarities from the device Gram kernel, and only
+        # the cluster heads' waveforms are copied to the host.  Any other
+        # duck-typed model goes through the reference's host loops.
+        resident = hasattr(spot_model, "shift_and_sep_resident")
+        if resident:
+            waves_dev, energies = spot_model.shift_and_sep_resident(mix_data, total_patch, Strict=1)
+            T_len = int(waves_dev.shape[1])
+        else:
+            sep_all = spot_model.shift_and_sep(mix_data, total_patch, Strict=1)
+            T_len = int(sep_all.shape[1])
 
         output_pair = []
         for i in range(len(bounds) - 1):
@@ -136,13 +146,17 @@ class MicArray(object):
                     if np.amax(np.abs(big.sample_offset - sample_gt[:, k])) < 3.5:
                         big_label = k
                         break
-            sep = sep_all[bounds[i]:bounds[i + 1]]
             patches = total_patch[bounds[i]:bounds[i + 1]]
-            powers, powers2 = [], []
-            for j in range(len(patches)):
-                sep[j, :] = sep[j, :] - np.mean(sep[j, :])                 # in place, as :291
-                powers.append(np.sum(sep[j, :] ** 2))
-                powers2.append(max_avg_power(sep[j, :]))
+            if resident:
+                powers = list(energies[bounds[i]:bounds[i + 1], 0])
+                powers2 = list(energies[bounds[i]:bounds[i + 1], 1])
+            else:
+                sep = sep_all[bounds[i]:bounds[i + 1]]
+                powers, powers2 = [], []
+                for j in range(len(patches)):
+                    sep[j, :] = sep[j, :] - np.mean(sep[j, :])                 # in place, as :291
+                    powers.append(np.sum(sep[j, :] ** 2))
+                    powers2.append(max_avg_power(sep[j, :]))
             c = big.center_pos()
             d = np.linalg.norm(c - self.mic_positions[0]) if c.shape[0] == 3 else 4
             if np.amax(powers2) < thr_new / (1 + d):
@@ -150,14 +164,21 @@ class MicArray(object):
             order = np.argsort(-1 * np.array(powers))                       # sorted by total power (:339)
             clusters = {}
             # the reference scales the trigger by the length of the LAST candidate row (:343)
-            min_trigger = self.MIN_TRIGGER_POWER / (3 * 48000) * sep[len(patches) - 1, :].shape[0]
+            min_trigger = self.MIN_TRIGGER_POWER / (3 * 48000) * T_len
+            sim = None
             for k in order:
                 d = np.linalg.norm(patches[k].center_pos() - self.mic_positions[0])
                 if powers2[k] < thr_new / (1 + d) or powers[k] < min_trigger:
                     continue
                 home = None
                 for head in clusters:
-                    if si_sdr(sep[k, :], sep[clusters[head][0]]) > -4:      # SI_SDR_THRESHOLD (:340)
+                    if resident:
+                        if sim is None:                                     # one Gram launch per coarse patch
+                            sim = spot_model.pair_sisdr(waves_dev[bounds[i]:bounds[i + 1]])
+                        s_kh = sim[k, clusters[head][0]]
+                    else:
+                        s_kh = si_sdr(sep[k, :], sep[clusters[head][0]])
+                    if s_kh > -4:                                           # SI_SDR_THRESHOLD (:340)
                         home = head
                         break
                 if home is None:
@@ -166,12 +187,17 @@ class MicArray(object):
                     clusters[home].append(k)
             if len(clusters) == 0:
                 continue
+            if resident:
+                heads = list(clusters.keys())
+                head_audio = waves_dev[[bounds[i] + h for h in heads]].cpu().numpy()
+                audio_of = {h: head_audio[n] for n, h in enumerate(heads)}
             for head in clusters:
                 _position, offs = weight_mean_pos(patches, powers, clusters[head])
                 centre = find_merge_center(offs, areas[i], self.mic_positions, centers[i])
                 if centre.center_pos() is None:
                     print("Warning some bug happen one source may be drop")
-                output_pair.append((centre, sep[head, :], powers[head], str(i) + '_' + str(head),
+                audio = audio_of[head] if resident else sep[head, :]
+                output_pair.append((centre, audio, powers[head], str(i) + '_' + str(head),
                                     {"audio_offset": patches[head].sample_offset, "localization_offset": offs},
                                     big_label))
         return output_pair

@@ -98,6 +98,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "asw_energies": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asw_pair_sisdr": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "asw_center_rows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "asw_srp_frames": (c_int, [c_int, c_int, c_int]),
     "asw_srp_cross_spectra": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

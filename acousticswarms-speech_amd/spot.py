@@ -183,6 +183,36 @@ class SpotModel:
         self.last_waveforms = wave
         return en.cpu().numpy()
 
+    def shift_and_sep_resident(self, input_channels, patch_list, Strict: int = 0, window: int = 12000):
+        """Device-resident variant for the fine stage: returns (waves, energies) where ``waves``
+        is a CUDA tensor [N,T] of the MEAN-REMOVED candidate outputs (sep/Mic_Array.py:291) that
+        stays on the GPU, and ``energies`` the host ndarray [N,2] = (power, power2).  Only the
+        energies (and later the few cluster heads) cross PCIe."""
+        import torch
+        self._need()
+        mix = torch.as_tensor(input_channels)
+        offs = offsets_from_patches(patch_list, mix.shape[0] - 1)
+        mix_d = mix.to(self.device, dtype=torch.float32).contiguous()
+        off_d = torch.from_numpy(offs).to(self.device)
+        wave, en = self.shift_and_sep_device(mix_d, off_d, Strict, want_wave=True, want_energy=True, window=window)
+        if wave.shape[0] > 0:
+            with torch.cuda.device(self.device):
+                native.check(native.lib().asw_center_rows(native.ptr(wave), wave.shape[0], wave.shape[1],
+                                                          native.current_stream()))
+        return wave, en.cpu().numpy()
+
+    def pair_sisdr(self, waves):
+        """SI-SDR matrix S[i][j] = si_sdr(est=waves[i], ref=waves[j]) computed on the GPU
+        (sep/helpers/eval_utils.py:11-39); returns a host ndarray [n,n] float64."""
+        import torch
+        n, T = waves.shape
+        out = torch.empty((n, n), dtype=torch.float64, device=waves.device)
+        if n > 0:
+            with torch.cuda.device(waves.device):
+                native.check(native.lib().asw_pair_sisdr(native.ptr(waves.contiguous()), n, T, native.ptr(out),
+                                                         native.current_stream()))
+        return out.cpu().numpy()
+
     def forward(self, mix, window_embedding):
         """Network.forward: mix [B,M,t] (already normalised), window_embedding [B,2] -> [B,1,t]
         (device tensor).  Rows are grouped by identical embedding because the window gate

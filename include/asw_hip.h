@@ -219,6 +219,10 @@ int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int taps, int 
 int asw_energies(const float* y, int B, int T, int window, double* scratch, double* out,
                  void* stream);
 
+/* In-place mean removal of every row (sep/Mic_Array.py:291, local_utils_3d.py:350): the
+ * stage loops centre each candidate output before comparing waveforms. */
+int asw_center_rows(float* y, int B, int T, void* stream);
+
 /* SI-SDR of every ordered pair (est=i, ref=j) of n waveforms (eval_utils.py:11-39;
  * call sites Mic_Array.py:353,432).  out [n][n] float64. */
 int asw_pair_sisdr(const float* y, int n, int T, double* out, void* stream);

@@ -87,3 +87,39 @@ def test_pipeline_with_hip_spot_model(mic_array):
         out = jm.forward(torch.from_numpy(mix[:, :24000 * 2]))
     _log(f"pipeline(HIP spot, random weights): n_final={len(out[0])} times={np.round(jm.times, 3)}")
     assert len(out) == 6
+
+
+def test_fine_stage_device_resident_equals_host_path(mic_array, golden):
+    """Spotform_Small_Patch_Parallel with the HIP model: the device-resident path (energies +
+    SI-SDR on the GPU, only cluster heads copied) must produce the same clusters as the
+    reference-style host loops on the downloaded waveforms."""
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    ma, mics, spk, mix = mic_array
+    g7 = golden("g7_srp_map")
+    spot = SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=32, precision="f16x3").to("cuda")
+
+    class HostOnly:                       # hides the resident entry point -> reference host loops
+        def __init__(self, m):
+            self.m = m
+
+        def shift_and_sep(self, *a, **k):
+            return self.m.shift_and_sep(*a, **k)
+
+    mix_t = torch.from_numpy(mix[:, :24000 * 2])
+    node = ma.SRP_node
+    with redirect_stdout(io.StringIO()):
+        node.set_map(g7["srp_map"])
+        coarse = node.local_source_adaptive()[:6]
+        ma.Relative_Threshold = 0.0
+        import copy
+        a = ma.Spotform_Small_Patch_Parallel(mix_t, copy.deepcopy(coarse), spot)
+        b = ma.Spotform_Small_Patch_Parallel(mix_t, copy.deepcopy(coarse), HostOnly(spot))
+    _log(f"fine stage: resident {len(a)} pairs, host {len(b)} pairs")
+    assert [p[3] for p in a] == [p[3] for p in b]
+    np.testing.assert_allclose([p[2] for p in a], [p[2] for p in b], rtol=1e-5)
+    for pa, pb in zip(a, b):
+        np.testing.assert_array_equal(pa[4]["audio_offset"], pb[4]["audio_offset"])
+        np.testing.assert_allclose(pa[4]["localization_offset"], pb[4]["localization_offset"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(pa[1], pb[1], rtol=0, atol=1e-6 * max(1.0, np.abs(pb[1]).max()))
