@@ -1,18 +1,19 @@
 // attention_mfma.hip -- bottleneck self-attention on the f32 MFMA pipe for the shapes the
-// spot network produces at T <= 49 152 samples: sequence L <= 192 (= T/256), head_dim 128.
+// spot network produces: sequence L = T/256 (188 at T = 48 000, 563 at T = 144 000; any
+// L <= 672 fits), head_dim 128.
 // nn.MultiheadAttention core inside nn.TransformerEncoderLayer
 // (sep/training/SpeakerLocalization/network.py:254): ctx = softmax(Q K^T / sqrt(hd)) V.
 //
-// One workgroup (4 waves) per (batch item, head, 32-query tile).  Everything a tile needs
-// fits in LDS, so there is no online-softmax rescaling and the arithmetic is an exact fp32
-// fmaf chain (v_mfma_f32_32x32x2_f32), like the fp32 GEMMs:
-//   phase 1  S[32][192] = (Q/sqrt(hd)) K^T   Q tile + all keys in LDS; 6 column tiles over 4 waves
+// One workgroup (4 waves) per (batch item, head, 32-query tile).  The whole score row of the
+// tile stays in LDS, so there is no online-softmax rescaling and the arithmetic is an exact
+// fp32 fmaf chain (v_mfma_f32_32x32x2_f32), like the fp32 GEMMs:
+//   phase 1  S[32][L] = (Q/sqrt(hd)) K^T   keys staged 96 at a time (3 column tiles, waves 0-2)
 //   softmax  row-wise over the L valid keys (8 lanes per row), padded keys -> 0
-//   phase 2  O[32][128] = P V                 V staged TRANSPOSED (Vt[n][key]) so the MFMA B
-//                                              operand is one ds_read_b128; 1 column tile per wave
+//   phase 2  O[32][128] = P V              V staged TRANSPOSED (Vt[n][key]) 96 keys at a time so
+//                                          the MFMA B operand is one ds_read_b128; wave w owns
+//                                          output columns [32w, 32w+32) across all key tiles
 // LDS rows are padded by 4 floats: the per-lane 16-byte operand reads are conflict free.
-// Longer sequences (T = 144 000 -> L = 563) use the tiled flash-style kernel in
-// misc_kernels.hip.
+// Sequences beyond 672 fall back to the flash-style VALU kernel in misc_kernels.hip.
 #include "asw_common.h"
 
 namespace {
@@ -20,10 +21,11 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int AQ = 32;            // queries per workgroup
-constexpr int AL = 192;           // padded key count
+constexpr int KT = 96;            // keys per staged tile (3 MFMA column tiles)
 constexpr int AD = 128;           // head_dim
 constexpr int LDQ = AD + 4;       // Q / K row stride (floats)
-constexpr int LDP = AL + 4;       // P / Vt row stride (floats)
+constexpr int LDV = KT + 4;       // Vt row stride (floats)
+constexpr int KVF = (KT * LDQ > AD * LDV) ? KT * LDQ : AD * LDV;   // floats of the shared K / Vt buffer
 
 __device__ __forceinline__ floatx16 mma_row(const float* a_row, const float* b_row, int ksteps, floatx16 acc) {
   // a_row / b_row already include this lane's (row, 4*(lane>>5)) offset; 8 k per iteration
@@ -38,18 +40,22 @@ __device__ __forceinline__ floatx16 mma_row(const float* a_row, const float* b_r
   return acc;
 }
 
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, int L, int d,
+// LP = L rounded up to a multiple of KT; the whole score row of a query tile lives in LDS
+// (Ps[AQ][LP+4]), so the softmax is exact and needs no running rescale.  LDS:
+// 17 KB (Q) + 50 KB (K / Vt tile) + 32*(LP+4)*4 B (scores): L <= 672 fits 160 KB.
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, int L, int LP, int d,
                                                              float* __restrict__ ctx) {
   extern __shared__ __align__(16) float smem[];
+  const int LDP = LP + 4;
   float* Qs = smem;                          // [AQ][LDQ]
-  float* Ps = Qs + AQ * LDQ;                 // [AQ][LDP]
-  float* KV = Ps + AQ * LDP;                 // K: [AL][LDQ]   then   Vt: [AD][LDP]
+  float* KV = Qs + AQ * LDQ;                 // K tile [KT][LDQ]   or   Vt tile [AD][LDV]
+  float* Ps = KV + KVF;                      // [AQ][LDP]
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AQ;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* base = qkv + (long)b * L * 3 * d + h * AD;
   const float scale = 1.0f / sqrtf((float)AD);
+  const int lr = lane & 31, lh = lane >> 5;
 
-  // ---- stage Q (scaled) and K; rows past L are zero
   for (int i = tid; i < AQ * (AD / 4); i += 256) {
     const int r = i / (AD / 4), c4 = i - r * (AD / 4);
     const int q = q0 + r;
@@ -58,40 +64,33 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
     *reinterpret_cast<float4*>(Qs + r * LDQ + c4 * 4) = v;
   }
-  for (int i = tid; i < AL * (AD / 4); i += 256) {
-    const int r = i / (AD / 4), c4 = i - r * (AD / 4);
-    float4 v = *reinterpret_cast<const float4*>(base + (long)(r < L ? r : 0) * 3 * d + d + c4 * 4);
-    if (r >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(KV + r * LDQ + c4 * 4) = v;
-  }
-  __syncthreads();
 
-  // ---- phase 1: S tiles.  wave w owns column tiles w and (w < 2) w + 4
-  const int lr = lane & 31, lh = lane >> 5;
-  for (int ct = wid; ct < AL / 32; ct += 4) {
-    floatx16 acc;
+  // ---- phase 1: S = (Q/sqrt(hd)) K^T, one 96-key tile at a time; waves 0..2 own a column tile
+  for (int k0 = 0; k0 < LP; k0 += KT) {
+    __syncthreads();                                   // previous tile consumed (and Q staged)
+    for (int i = tid; i < KT * (AD / 4); i += 256) {
+      const int r = i / (AD / 4), c4 = i - r * (AD / 4);
+      const int j = k0 + r;
+      float4 v = *reinterpret_cast<const float4*>(base + (long)(j < L ? j : 0) * 3 * d + d + c4 * 4);
+      if (j >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(KV + r * LDQ + c4 * 4) = v;
+    }
+    __syncthreads();
+    if (wid < KT / 32) {
+      floatx16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    acc = mma_row(Qs + lr * LDQ + lh * 4, KV + (ct * 32 + lr) * LDQ + lh * 4, AD / 8, acc);
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = mma_row(Qs + lr * LDQ + lh * 4, KV + (wid * 32 + lr) * LDQ + lh * 4, AD / 8, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      Ps[row * LDP + ct * 32 + lr] = acc[r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        Ps[row * LDP + k0 + wid * 32 + lr] = acc[r];
+      }
     }
   }
   __syncthreads();
 
-  // ---- stage V transposed over the K buffer (all waves are past phase 1) ...
-  for (int i = tid; i < AL * (AD / 4); i += 256) {
-    const int j = i / (AD / 4), c4 = i - j * (AD / 4);
-    float4 v = *reinterpret_cast<const float4*>(base + (long)(j < L ? j : 0) * 3 * d + 2 * d + c4 * 4);
-    if (j >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    KV[(c4 * 4 + 0) * LDP + j] = v.x;
-    KV[(c4 * 4 + 1) * LDP + j] = v.y;
-    KV[(c4 * 4 + 2) * LDP + j] = v.z;
-    KV[(c4 * 4 + 3) * LDP + j] = v.w;
-  }
-  // ---- ... and the row softmax: 8 lanes per query row
+  // ---- row softmax over the L valid keys: 8 lanes per query row, padded keys -> 0
   {
     const int row = tid >> 3, sub = tid & 7;
     float* pr = Ps + row * LDP;
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     float s = 0.f;
-    for (int j = sub; j < AL; j += 8) {
+    for (int j = sub; j < LP; j += 8) {
       const float e = j < L ? expf(pr[j] - m) : 0.f;
       pr[j] = e;
       s += e;
@@ -108,21 +107,33 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float inv = 1.0f / s;
-    for (int j = sub; j < AL; j += 8) pr[j] *= inv;
+    for (int j = sub; j < LP; j += 8) pr[j] *= inv;
   }
-  __syncthreads();
 
-  // ---- phase 2: O column tile `wid` = P @ V
-  {
-    floatx16 acc;
+  // ---- phase 2: O = P V, V staged transposed (Vt[n][key]) per 96-key tile; wave w owns O
+  //      columns [32w, 32w+32) and keeps its accumulator across the tiles
+  floatx16 oacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    acc = mma_row(Ps + lr * LDP + lh * 4, KV + (wid * 32 + lr) * LDP + lh * 4, AL / 8, acc);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (q < L) ctx[((long)b * L + q) * d + h * AD + wid * 32 + lr] = acc[r];
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+  for (int k0 = 0; k0 < LP; k0 += KT) {
+    __syncthreads();                                   // softmax done / previous Vt tile consumed
+    for (int i = tid; i < KT * (AD / 4); i += 256) {
+      const int r = i / (AD / 4), c4 = i - r * (AD / 4);
+      const int j = k0 + r;
+      float4 v = *reinterpret_cast<const float4*>(base + (long)(j < L ? j : 0) * 3 * d + 2 * d + c4 * 4);
+      if (j >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      KV[(c4 * 4 + 0) * LDV + r] = v.x;
+      KV[(c4 * 4 + 1) * LDV + r] = v.y;
+      KV[(c4 * 4 + 2) * LDV + r] = v.z;
+      KV[(c4 * 4 + 3) * LDV + r] = v.w;
     }
+    __syncthreads();
+    oacc = mma_row(Ps + lr * LDP + k0 + lh * 4, KV + (wid * 32 + lr) * LDV + lh * 4, KT / 8, oacc);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (q < L) ctx[((long)b * L + q) * d + h * AD + wid * 32 + lr] = oacc[r];
   }
 }
 
@@ -131,18 +142,19 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 namespace asw {
 // returns 1 when the shape is not an MFMA-kernel case
 int attention_mfma(const float* qkv, int B, int L, int d, int nhead, float* ctx, hipStream_t s) {
-  if (d / nhead != AD || L > AL) return 1;
-  const size_t smem = sizeof(float) * ((size_t)AQ * LDQ + (size_t)AQ * LDP + (size_t)AL * LDQ);
-  static_assert((size_t)AL * LDQ >= (size_t)AD * LDP, "Vt must fit in the K buffer");
-  static bool attr = false;
-  if (!attr) {
+  if (d / nhead != AD) return 1;
+  const int LP = cdiv(L, KT) * KT;
+  const size_t smem = sizeof(float) * ((size_t)AQ * LDQ + (size_t)KVF + (size_t)AQ * (LP + 4));
+  if (smem > 160 * 1024) return 1;                     // very long sequences: flash-style VALU kernel
+  static size_t attr = 0;
+  if (smem > attr) {
     ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr = true;
+    attr = smem;
   }
   dim3 grid(cdiv(L, AQ), nhead, B);
   ProfScope prof(s, "attention_mfma", 4.0 * B * nhead * (double)L * L * AD);
-  hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), smem, s, qkv, L, d, ctx);
+  hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), smem, s, qkv, L, LP, d, ctx);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }

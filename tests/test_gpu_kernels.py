@@ -163,7 +163,7 @@ def test_linear_residual_layernorm(ops, d, f, L, B):
 
 
 @pytest.mark.parametrize("L,d,nhead,B", [(19, 128, 8, 3), (188, 1024, 8, 2), (300, 1024, 8, 1), (150, 1024, 8, 2),
-                                         (192, 1024, 8, 1), (33, 1024, 8, 2), (47, 512, 4, 2)])
+                                         (192, 1024, 8, 1), (33, 1024, 8, 2), (47, 512, 4, 2), (563, 1024, 8, 1), (700, 1024, 8, 1)])
 def test_attention(ops, L, d, nhead, B):
     qkv = _rand(B, L, 3 * d, seed=28)
     hd = d // nhead
