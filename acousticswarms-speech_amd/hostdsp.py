@@ -29,18 +29,19 @@ def stft_frames(x: np.ndarray, nfft: int, hop: int) -> np.ndarray:
 
 def frame_rms(y: np.ndarray, frame_length: int = 1024, hop_length: int = 256) -> np.ndarray:
     """librosa.feature.rms(y=, frame_length=, hop_length=) (centered, zero padded):
-    returns [1, 1 + len(y)//hop]."""
+    returns [1, 1 + len(y)//hop].  The samples are squared once and the frames are a strided
+    view of that array (no gather, no per-frame re-squaring)."""
     pad = frame_length // 2
     yp = np.pad(y, (pad, pad), mode="constant")
-    n = 1 + (yp.shape[0] - frame_length) // hop_length
-    idx = np.arange(frame_length)[None, :] + hop_length * np.arange(n)[:, None]
-    power = np.mean(np.abs(yp[idx]) ** 2, axis=1)
-    return np.sqrt(power)[None, :]
+    sq = yp * yp
+    frames = np.lib.stride_tricks.sliding_window_view(sq, frame_length)[::hop_length]
+    return np.sqrt(np.mean(frames, axis=1))[None, :]
 
 
-def nonsilent_intervals(y, top_db=60, ref=np.max, frame_length=2048, hop_length=512):
-    """librosa.effects.split: frames whose RMS is within ``top_db`` of ``ref``."""
-    rms = frame_rms(y, frame_length, hop_length)[0]
+def nonsilent_intervals(y, top_db=60, ref=np.max, frame_length=2048, hop_length=512, rms=None):
+    """librosa.effects.split: frames whose RMS is within ``top_db`` of ``ref``.  ``rms`` may
+    carry frame_rms(y, frame_length, hop_length) when the caller already has it."""
+    rms = frame_rms(y, frame_length, hop_length)[0] if rms is None else rms[0]
     amin = 1e-5
     ref_value = np.abs(ref(rms)) if callable(ref) else np.abs(ref)
     db = 10.0 * np.log10(np.maximum(amin ** 2, rms ** 2)) - 10.0 * np.log10(max(amin ** 2, ref_value ** 2))
@@ -68,11 +69,12 @@ def si_sdr(est: np.ndarray, ref: np.ndarray) -> float:
 def split_wav(wav: np.ndarray, top_db: float = 18):
     """Voiced segments of 1000..4000 samples, sep/helpers/eval_utils.py:43-70."""
     lo, hi = 1000, 4000
-    peak = np.amax(frame_rms(wav, 1024, 256))
+    rms = frame_rms(wav, 1024, 256)
+    peak = np.amax(rms)
     if peak < 0.04:
-        iv = nonsilent_intervals(wav, top_db=top_db, ref=0.04, frame_length=1024, hop_length=256)
+        iv = nonsilent_intervals(wav, top_db=top_db, ref=0.04, frame_length=1024, hop_length=256, rms=rms)
     else:
-        iv = nonsilent_intervals(wav, top_db=top_db, frame_length=1024, hop_length=256)
+        iv = nonsilent_intervals(wav, top_db=top_db, frame_length=1024, hop_length=256, rms=rms)
     segs = []
     for a, b in iv:
         n = b - a

@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASW_LIB_PATH") or os.path.join(_HERE, "libasw_hip.so")   # env: A/B builds only
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["asw_common.cpp", "convgemm.hip", "prep_kernels.hip", "misc_kernels.hip", "attention_mfma.hip", "srp_kernels.hip",
+SOURCES = ["asw_common.cpp", "convgemm.hip", "prep_kernels.hip", "misc_kernels.hip", "attention_mfma.hip", "srp_kernels.hip", "search_host.cpp",
            "spot_model.hip"]
 
 
@@ -99,6 +99,10 @@ SIGNATURES = {
     "asw_energies": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asw_pair_sisdr": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "asw_center_rows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "asw_search_area": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_double, c_double,
+                                POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                POINTER(c_void_p)]),
+    "asw_free": (None, [c_void_p]),
     "asw_srp_frames": (c_int, [c_int, c_int, c_int]),
     "asw_srp_cross_spectra": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -227,6 +227,19 @@ int asw_center_rows(float* y, int B, int T, void* stream);
  * call sites Mic_Array.py:353,432).  out [n][n] float64. */
 int asw_pair_sisdr(const float* y, int n, int T, double* out, void* stream);
 
+/* HOST function (no GPU): breadth-first subdivision of one coarse hypercube into the fine
+ * candidate hypercubes -- search_area / binary_area_divide_width
+ * (sep/helpers/local_utils_3d.py:212-335) with Patch.check_out / hyperbola_sample
+ * (sep/Traditional_SP/Patch_3D.py:40-47,69-87).  points [3][n_pts] float64 (the coarse patch's
+ * area_points), mic [M][3]; offset/width [M-1] are IN/OUT (check_out mutates the caller's
+ * patch, as the reference does); ub [M-1] physical TDoA bounds or NULL.  Results are
+ * malloc'ed: child_offset/child_width [n_children][M-1], child_count [n_children] and the
+ * concatenated point indices child_index; release each with asw_free. */
+int asw_search_area(const double* points, int n_pts, const double* mic, int M, double* offset,
+                    double* width, const double* ub, double sound_speed, double fs, int* n_children,
+                    double** child_offset, double** child_width, int** child_count, int** child_index);
+void asw_free(void* p);
+
 /* SRP-PHAT pruning map (sep/Traditional_SP/SRP_Prunning.py:387-434), two stages.
  *
  * asw_srp_cross_spectra: for each of n_windows analysis windows (start w*step, length

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic: cProfile of one JointModel.forward (host-side hot spots of the search)."""
+import cProfile
+import io
+import os
+import pstats
+import sys
+from contextlib import redirect_stdout
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+from acousticswarms_speech_amd.config import FULL
+from acousticswarms_speech_amd.joint import JointModel
+from acousticswarms_speech_amd.scenes import make_scene
+from acousticswarms_speech_amd.spot import SpotModel
+from acousticswarms_speech_amd.weights import make_spot_state_dict
+
+scene = make_scene(1001, 3, 7, 48000)
+spot = SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=64, precision="f16x3").to("cuda")
+jm = JointModel(spot, None, device="cuda")
+mix = torch.from_numpy(scene.mix)
+with redirect_stdout(io.StringIO()):
+    jm.setup(scene.mic_positions, scene.speaker_range)
+    jm.forward(mix)
+pr = cProfile.Profile()
+with redirect_stdout(io.StringIO()):
+    pr.enable()
+    jm.forward(mix)
+    pr.disable()
+print("times", [round(t * 1e3, 1) for t in jm.times])
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
+print(s.getvalue()[:6000])
