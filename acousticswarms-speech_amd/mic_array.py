@@ -125,21 +125,43 @@ class MicArray(object):
             total_patch.extend(fine)
             bounds.append(self.spotforming_times)
 
+        # one rank per GPU (shard.ShardedSpotModel): whole coarse patches are dealt to ranks so
+        # the per-patch clustering below stays local; energies are all-gathered (the stage's one
+        # collective) and only the finished output tuples travel.
+        sharded = getattr(spot_model, "world", 1) > 1
+        n_groups = len(bounds) - 1
+        mine = spot_model.my_groups([bounds[i + 1] - bounds[i] for i in range(n_groups)]) if sharded \
+            else list(range(n_groups))
+        if sharded:
+            gbounds = bounds
+            total_patch_all = total_patch
+            total_patch, bounds = [], [0]
+            for i in mine:
+                total_patch.extend(total_patch_all[gbounds[i]:gbounds[i + 1]])
+                bounds.append(len(total_patch))
+        slot = {g: n for n, g in enumerate(mine)}              # coarse patch -> local group slot
+
         # the hot call.  With the HIP spot model the N x T outputs stay on the GPU: energies come
         # from the device reduction, SI-SDR similarities from the device Gram kernel, and only
         # the cluster heads' waveforms are copied to the host.  Any other
         # duck-typed model goes through the reference's host loops.
         resident = hasattr(spot_model, "shift_and_sep_resident")
-        if resident:
+        if len(total_patch) == 0:                          # a rank that was dealt no coarse patch
+            waves_dev, energies, sep_all = None, np.zeros((0, 2)), None
+            T_len = int(mix_data.shape[1])
+        elif resident:
             waves_dev, energies = spot_model.shift_and_sep_resident(mix_data, total_patch, Strict=1)
             T_len = int(waves_dev.shape[1])
         else:
             sep_all = spot_model.shift_and_sep(mix_data, total_patch, Strict=1)
             T_len = int(sep_all.shape[1])
+        if sharded and resident:
+            self.fine_energies = spot_model.all_gather_groups(energies, mine, gbounds)
 
         output_pair = []
-        for i in range(len(bounds) - 1):
-            big = candidate_finished[i]
+        for g in mine:
+            i = slot[g]                                                     # local slot of coarse patch g
+            big = candidate_finished[g]
             big_label = -1
             if sample_gt is not None:
                 for k in range(sample_gt.shape[1]):
@@ -193,13 +215,15 @@ class MicArray(object):
                 audio_of = {h: head_audio[n] for n, h in enumerate(heads)}
             for head in clusters:
                 _position, offs = weight_mean_pos(patches, powers, clusters[head])
-                centre = find_merge_center(offs, areas[i], self.mic_positions, centers[i])
+                centre = find_merge_center(offs, areas[g], self.mic_positions, centers[g])
                 if centre.center_pos() is None:
                     print("Warning some bug happen one source may be drop")
                 audio = audio_of[head] if resident else sep[head, :]
-                output_pair.append((centre, audio, powers[head], str(i) + '_' + str(head),
+                output_pair.append((centre, audio, powers[head], str(g) + '_' + str(head),
                                     {"audio_offset": patches[head].sample_offset, "localization_offset": offs},
                                     big_label))
+        if sharded:
+            output_pair = spot_model.gather_pairs(output_pair)
         return output_pair
 
     # ---- stage 4: global non-max suppression (sep/Mic_Array.py:399-500) -----------------

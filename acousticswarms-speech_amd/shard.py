@@ -52,7 +52,7 @@ class ShardedScorer:
 
     def score(self, mix, offsets: np.ndarray, device=None) -> np.ndarray:
         import torch
-        N = int(offsets.shape[0])
+        N = len(offsets)                                     # ndarray [N,P] or a list of patches
         b = shard_bounds(N, self.world)
         lo, hi = b[self.rank], b[self.rank + 1]
         local = self.local_score(mix, offsets[lo:hi])
@@ -67,3 +67,129 @@ class ShardedScorer:
         self.dist.all_gather_into_tensor(out, buf, group=self.group)   # the stage's one exchange
         out = out.view(self.world, width, 2).cpu().numpy()
         return np.concatenate([out[r, :b[r + 1] - b[r]] for r in range(self.world)], axis=0)
+
+
+class ShardedSpotModel:
+    """Duck-typed spot model for ``MicArray`` / ``JointModel`` with one rank per GPU.
+
+    Every rank runs the same (deterministic) host search on the same mixture; the candidate
+    evaluations are what is sharded:
+      * coarse stage: ``shift_and_score`` -> contiguous shard + all-gather of [N,2] energies;
+      * fine stage:   ``MicArray.Spotform_Small_Patch_Parallel`` asks ``my_groups`` for the
+        coarse patches this rank owns (LPT-balanced whole groups), evaluates only those through
+        the wrapped model, all-gathers the energies (``all_gather_groups``) and the finished
+        output tuples (``gather_pairs``, object gather of a few cluster heads).
+    Replaces nn.DataParallel's per-call replicate/scatter/gather
+    (sep/training/JointModel/network.py:30,93).  ``inner`` is a SpotModel (HIP) or any object
+    with the reference's ``shift_and_sep`` surface (used by the gloo CPU tests)."""
+
+    def __init__(self, inner, group=None, device=None):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("ShardedSpotModel needs an initialised torch.distributed process group")
+        self.inner, self.group, self.dist = inner, group, dist
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        self._scorer = ShardedScorer(self._local_score, group)
+        self._strict = 0
+        # the device-resident fine stage is offered only when the wrapped model has it
+        if hasattr(inner, "shift_and_sep_resident"):
+            self.shift_and_sep_resident = inner.shift_and_sep_resident
+            self.pair_sisdr = inner.pair_sisdr
+
+    def to(self, device):
+        if hasattr(self.inner, "to"):
+            self.inner.to(device)
+        return self
+
+    # ---- candidate-sharded scoring -------------------------------------------------------
+    def _local_score(self, mix, patches):
+        if len(patches) == 0:
+            return np.zeros((0, 2))
+        if hasattr(self.inner, "shift_and_score"):
+            return self.inner.shift_and_score(mix, patches, Strict=self._strict, keep_waveforms=False)
+        from .hostdsp import max_avg_power
+        sep = self.inner.shift_and_sep(mix, patches, Strict=self._strict)
+        out = np.zeros((sep.shape[0], 2))
+        for i in range(sep.shape[0]):
+            x = sep[i, :] - np.mean(sep[i, :])
+            out[i] = (np.sum(x ** 2), max_avg_power(x))
+        return out
+
+    def shift_and_score(self, mix, patch_list, Strict=0, keep_waveforms=False):
+        if keep_waveforms:
+            raise RuntimeError("sharded scoring returns energies only")
+        self._strict = Strict
+
+        return self._scorer.score(mix, list(patch_list), device=self.device)
+
+    def shift_and_sep(self, mix, patch_list, Strict=0, save_input=False):
+        """Reference surface on the LOCAL candidates handed in (the fine stage passes only
+        this rank's groups)."""
+        return self.inner.shift_and_sep(mix, patch_list, Strict=Strict)
+
+    # ---- fine-stage group sharding -------------------------------------------------------
+    def my_groups(self, sizes):
+        return shard_groups(sizes, self.world)[self.rank]
+
+    def all_gather_groups(self, local_energies, mine, bounds):
+        """All-gather of the fine-stage energies: local rows are this rank's groups in
+        ``mine`` order; returns the full [N,2] table in the global candidate order."""
+        import torch
+        sizes = [bounds[i + 1] - bounds[i] for i in range(len(bounds) - 1)]
+        owners = shard_groups(sizes, self.world)
+        width = max(1, max(sum(sizes[g] for g in o) for o in owners))
+        buf = torch.zeros((width, 2), dtype=torch.float64, device=self.device)
+        loc = torch.as_tensor(np.asarray(local_energies, dtype=np.float64).reshape(-1, 2))
+        buf[:loc.shape[0]] = loc.to(self.device)
+        out = torch.empty((self.world * width, 2), dtype=torch.float64, device=self.device)
+        self.dist.all_gather_into_tensor(out, buf, group=self.group)
+        out = out.view(self.world, width, 2).cpu().numpy()
+        full = np.zeros((bounds[-1], 2))
+        for r, o in enumerate(owners):
+            pos = 0
+            for g in o:
+                full[bounds[g]:bounds[g + 1]] = out[r, pos:pos + sizes[g]]
+                pos += sizes[g]
+        return full
+
+    def gather_pairs(self, local_pairs):
+        """Object all-gather of the finished (centre, audio, power, "g_head", ...) tuples,
+        merged back into coarse-patch order (the order the single-GPU loop emits)."""
+        box = [None] * self.world
+        self.dist.all_gather_object(box, local_pairs, group=self.group)
+        merged = [p for part in box for p in part]
+        key = lambda p: int(p[3].split("_")[0])              # stable: heads keep their per-group order
+        return sorted(merged, key=key)
+
+
+def localize_batch(joint_model, mixes, group=None):
+    """A batch of mixtures over the ranks of one node (BASELINE config "batch of 64 mixtures"):
+    with at least as many mixtures as ranks the cheapest partition is by whole mixture --
+    contiguous balanced blocks, each rank runs the complete search of its mixtures on its own
+    GPU with no per-candidate traffic -- followed by ONE object all-gather of the per-mixture
+    results.  (Fewer mixtures than ranks: wrap the spot model in ``ShardedSpotModel`` instead,
+    which shards the candidates of a single mixture.)
+
+    ``joint_model.spot_model`` must be the plain per-rank model here.  Returns, on every rank and
+    in mixture order, a list of dicts {centres [K,3], powers [K], names, spot_times, times[5]}."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if on else 0
+    world = dist.get_world_size(group) if on else 1
+    if getattr(joint_model.spot_model, "world", 1) > 1:
+        raise RuntimeError("localize_batch shards by mixture: pass the un-sharded per-rank spot model")
+    b = shard_bounds(len(mixes), world)
+    local = []
+    for k in range(b[rank], b[rank + 1]):
+        patches, _audio_loc, _audio, _d0, _d1, spot_times = joint_model.forward(mixes[k])
+        local.append((k, {"centres": np.array([p[0].center_pos() for p in patches]).reshape(-1, 3),
+                          "powers": np.array([p[2] for p in patches]),
+                          "names": [p[3] for p in patches],
+                          "spot_times": spot_times, "times": list(joint_model.times)}))
+    if world == 1:
+        return [r for _k, r in local]
+    box = [None] * world
+    dist.all_gather_object(box, local, group=group)
+    merged = sorted((kr for part in box for kr in part), key=lambda kr: kr[0])
+    return [r for _k, r in merged]

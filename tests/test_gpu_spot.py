@@ -163,3 +163,31 @@ def test_error_behaviour():
         m.shift_and_sep(torch.zeros(7, 1000), [np.zeros(5)])      # offsets / channels mismatch
     with pytest.raises(RuntimeError):
         SpotModel(SpotConfig(channels=8, encoder_channels=64, ffw_dim=32)).to("cuda")
+
+
+def test_sixteen_mic_dense_candidates_vs_oracle():
+    """BASELINE config 5 shape: 16 microphones (15 pairs), candidates taken from the dense TDoA
+    lattice instead of SRP-PHAT.  Same bar as the 7-mic path: >= 80 dB against the oracle on the
+    same seeded weights, energies to 1e-4."""
+    import dataclasses
+    from acousticswarms_speech_amd.config import SMALL
+    from acousticswarms_speech_amd.dense_grid import dense_tdoa_candidates
+    from acousticswarms_speech_amd.scenes import make_scene
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    from oracle import spot_ref
+    cfg = dataclasses.replace(SMALL, n_mics=16)
+    sd = make_spot_state_dict(cfg, 33)
+    m = _model(cfg, 33, batch=8)
+    sc = make_scene(7, 3, 16, 5000)
+    mix = torch.from_numpy(sc.mix)
+    offs, _counts, patches = dense_tdoa_candidates(sc.mic_positions, [-1.0, 1.0, 0.4, 2.0, 0.1, 0.5], width=2, step=0.05)
+    pick = patches[::max(1, len(patches) // 19)][:19]          # ragged against the batch of 8
+    assert pick[0].sample_offset.shape == (15,)
+    for strict in (0, 1):
+        y = m.shift_and_sep(mix, pick, Strict=strict)
+        ref = spot_ref.shift_and_sep(sd, cfg, mix, [p.sample_offset for p in pick], strict=strict)
+        per = [snr_db(y[i], ref[i]) for i in range(len(pick))]
+        _log(f"16-mic shift_and_sep strict={strict}: min SNR {min(per):.1f} dB over {len(pick)} candidates")
+        assert min(per) > 80.0
+        en = m.shift_and_score(mix, pick, Strict=strict, window=1500)
+        np.testing.assert_allclose(en, spot_ref.candidate_energies(ref, 1500), rtol=1e-4)

@@ -138,3 +138,25 @@ def test_find_merge_center_fallback():
     far = np.array([200.0, -200.0])
     p = find_merge_center(far, area, mics, np.array([1.0, 1.0, 0.3]))
     assert p.area_points is None and p.center_pos().tolist() == [1.0, 1.0, 0.3]
+
+
+def test_dense_tdoa_lattice_invariants():
+    """16-mic dense lattice (BASELINE config 5, SRP bypassed): every grid point belongs to exactly
+    one cube, cube centres are multiples of the width, members lie within +-width/2."""
+    from acousticswarms_speech_amd.dense_grid import dense_tdoa_candidates, roi_grid
+    from acousticswarms_speech_amd.patch import pair_offsets
+    from acousticswarms_speech_amd.scenes import desk_mics
+    mics = np.asarray(desk_mics(np.random.default_rng(5), 16)[0])
+    roi = [-1.0, 1.0, 0.4, 2.0, 0.1, 0.5]
+    for width in (2, 4):
+        offs, counts, patches = dense_tdoa_candidates(mics, roi, width=width, step=0.05)
+        n_pts = roi_grid(roi, 0.05).shape[1]
+        assert offs.shape[1] == 15 and counts.sum() == n_pts and len(patches) == len(offs)
+        assert np.all(offs % width == 0)
+        assert len(np.unique(offs, axis=0)) == len(offs)
+        for p, c in list(zip(patches, counts))[::97]:
+            t = pair_offsets(p.area_points, mics)
+            assert p.area_points.shape[1] == c
+            assert np.all(np.abs(t - p.sample_offset[:, None]) <= width / 2 + 1e-9)
+            assert np.all(p.hyperbola_sample(t) == 1)
+    assert len(offs) > 1000          # thousands of candidates even in this small ROI

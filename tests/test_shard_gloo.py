@@ -79,3 +79,128 @@ def test_two_rank_all_gather_matches_single_process():
 def test_single_process_passthrough():
     offs = np.arange(30).reshape(5, 6)
     np.testing.assert_array_equal(ShardedScorer(_fake_score).score(None, offs), _fake_score(None, offs))
+
+
+# ---------------------------------------------------------------- whole search, two ranks
+def _pipeline_worker(rank, world, port, q):
+    """Every rank runs MicArray's four stages on the same mixture through ShardedSpotModel
+    (surrogate scorer, gloo): candidate evaluations are sharded, results must equal the
+    single-process reference trace (fixture g10)."""
+    import io
+    from contextlib import redirect_stdout
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from acousticswarms_speech_amd.mic_array import MicArray
+        from acousticswarms_speech_amd.shard import ShardedSpotModel
+        from tests.golden.make_golden_search import ROI, scene_in_roi
+        from tests.golden.surrogate import SurrogateSpot
+        gdir = os.path.join(os.path.dirname(__file__), "golden")
+        g7 = np.load(os.path.join(gdir, "g7_srp_map.npz"))
+        mics, _spk, mix = scene_in_roi()
+        with redirect_stdout(io.StringIO()):
+            ma = MicArray(mics, Spk_Range=ROI)
+            node = ma.SRP_node
+            node.SRP_Map_WINDOW_new = lambda signal, window=36000: node.set_map(g7["srp_map"])
+            inner = SurrogateSpot()
+            spot = ShardedSpotModel(inner)
+            mix_t = torch.from_numpy(mix)
+            p1, _ = ma.Apply_SRP_PHAT(mix_t)
+            p2 = ma.Spotform_Big_Patch(mix_t, p1, spot)
+            kept = [int(np.flatnonzero([x is p for x in p1])[0]) for p in p2]
+            pairs = ma.Spotform_Small_Patch_Parallel(mix_t, p2, spot)
+            _audio, final, spot_times, _ = ma.Clustering_new(pairs)
+        q.put((rank, kept, [p[3] for p in pairs], np.array([p[2] for p in pairs]),
+               np.stack([p[0].center_pos() for p in pairs]), [p[3] for p in final],
+               np.stack([p[0].center_pos() for p in final]), spot_times, sum(n for n, _s in inner.calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_search_matches_reference_trace():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g10_stage_trace.npz"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    evaluated = 0
+    for rank, kept, names, power, centre, fnames, fcentre, spot_times, n_eval in res:
+        assert kept == g["kept"].tolist()
+        assert names == g["pair_names"].tolist()
+        np.testing.assert_allclose(power, g["pair_power"], rtol=1e-5)
+        np.testing.assert_allclose(centre, g["pair_center"], atol=1e-6)
+        assert fnames == g["final_names"].tolist()
+        np.testing.assert_allclose(fcentre, g["final_center"], atol=1e-6)
+        assert spot_times == int(g["spot_times"])
+        evaluated += n_eval
+    # the two ranks together evaluated every candidate exactly once
+    assert evaluated == int(sum(c[0] for c in g["calls"].tolist()))
+
+
+# ---------------------------------------------------------------- batch of mixtures, two ranks
+def _batch_setup():
+    import io
+    from contextlib import redirect_stdout
+    from acousticswarms_speech_amd.joint import JointModel
+    from tests.golden.make_golden_search import ROI, scene_in_roi
+    from tests.golden.surrogate import SurrogateSpot
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    g7 = np.load(os.path.join(gdir, "g7_srp_map.npz"))
+    mics, _spk, mix = scene_in_roi()
+    jm = JointModel(SurrogateSpot())
+    with redirect_stdout(io.StringIO()):
+        jm.setup(mics, ROI)
+    node = jm.Mic_processor.SRP_node
+    node.SRP_Map_WINDOW_new = lambda signal, window=36000: node.set_map(g7["srp_map"])   # no GPU here
+    mixes = [torch.from_numpy(mix * gain) for gain in (1.0, 0.6, 0.35)]
+    return jm, mixes
+
+
+def _batch_worker(rank, world, port, q):
+    import io
+    from contextlib import redirect_stdout
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from acousticswarms_speech_amd.shard import localize_batch
+        jm, mixes = _batch_setup()
+        with redirect_stdout(io.StringIO()):
+            out = localize_batch(jm, mixes)
+        q.put((rank, [(r["centres"], r["powers"], r["names"], r["spot_times"]) for r in out],
+               len(jm.spot_model.calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_mixture_batch_matches_single_process():
+    import io
+    from contextlib import redirect_stdout
+    from acousticswarms_speech_amd.shard import localize_batch
+    jm, mixes = _batch_setup()
+    with redirect_stdout(io.StringIO()):
+        want = localize_batch(jm, mixes)                     # no process group: plain loop
+    assert len(want) == 3 and len(want[0]["names"]) >= 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _rank, out, _n in res:
+        assert len(out) == 3
+        for got, w in zip(out, want):
+            np.testing.assert_array_equal(got[0], w["centres"])
+            np.testing.assert_array_equal(got[1], w["powers"])
+            assert got[2] == w["names"] and got[3] == w["spot_times"]
+    # rank 0 ran two mixtures, rank 1 one (2 spot calls per mixture: coarse + fine)
+    assert [n for _r, _o, n in res] == [4, 2]
