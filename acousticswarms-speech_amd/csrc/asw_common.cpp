@@ -26,6 +26,7 @@ namespace {
 struct Rec { std::string name; double work; hipEvent_t e0, e1; };
 std::mutex g_mu;
 bool g_on = false;
+bool g_detail = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t take_event() {
@@ -41,6 +42,7 @@ std::string prof_name(const char* base, int bm, int bn, int bk, bool ln, bool st
   snprintf(b, sizeof b, "%s<%d,%d,%d,%s>", base, bm, bn, bk, ln ? "ln" : stats ? "stats" : "plain");
   return b;
 }
+bool prof_detail() { return g_detail; }
 ProfScope::ProfScope(hipStream_t s, const std::string& name, double work) : slot(-1), stream(s) {
   if (!g_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -61,6 +63,7 @@ extern "C" int asw_profile_enable(int on) {
   for (auto& r : asw::g_recs) { asw::g_pool.push_back(r.e0); asw::g_pool.push_back(r.e1); }
   asw::g_recs.clear();
   asw::g_on = on != 0;
+  asw::g_detail = on == 2;                 // 2: GEMM launch names carry their shape
   return ASW_OK;
 }
 
@@ -80,7 +83,7 @@ extern "C" int asw_profile_report(char* buf, size_t cap) {
   off += snprintf(buf + off, cap - off, "{");
   bool first = true;
   for (auto& kv : agg) {
-    if (off + 160 >= cap) break;
+    if (off + 224 >= cap) break;
     off += snprintf(buf + off, cap - off, "%s\"%s\":{\"launches\":%ld,\"ms\":%.6f,\"work\":%.6e}", first ? "" : ",",
                     kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.work);
     first = false;

@@ -46,6 +46,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 #include <string>
 namespace asw {
 std::string prof_name(const char* base, int bm, int bn, int bk, bool ln, bool stats);
+bool prof_detail();
 struct ProfScope {
   ProfScope(hipStream_t s, const std::string& name, double work);
   ~ProfScope();

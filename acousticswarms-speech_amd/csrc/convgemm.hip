@@ -56,13 +56,13 @@ struct RowsContig {
 template <int BM, int BN, int WM, int WN, bool LN, bool STATS, bool RESID, bool MUL, typename RowMap>
 __device__ __forceinline__ void epilogue(  // WM*WN waves (4 or 8)
 floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
-                                         float* smem, float acc_scale, const RowMap& rowmap) {
+                                         float* smem, float acc_scale, const RowMap& rowmap, const dim3 tile) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDC = BN + 4;
   float* Ct = smem;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  const int b = blockIdx.z, n0 = blockIdx.y * BN;
+  const int b = tile.z, n0 = tile.y * BN;
   float st0 = 0.f, sq0 = 0.f, st1 = 0.f, sq1 = 0.f;
   const int half_mod = p.chan_mod >> 1;
 #pragma unroll
@@ -182,10 +182,27 @@ floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
       for (int w = 0; w < WM * WN; ++w) s += red[w * 4 + tid];
       // slot layout is independent of the tile shape: stats_stride slots per batch item (the
       // launcher zero-fills the buffer, smaller grids simply leave slots at zero)
-      const long part = (long)b * p.stats_stride + (long)blockIdx.x * gridDim.y + blockIdx.y;
+      const long part = (long)b * p.stats_stride + (long)tile.x * gridDim.y + tile.y;
       p.stats[part * 4 + tid] = s;
     }
   }
+}
+
+// Activation loads go through a raw buffer descriptor: an offset outside [0, bytes) -- the
+// zero padding of the convolution, rows past the end of the sequence, or a disabled lane --
+// makes the hardware return zeros, so the staging loads carry no branch and no
+// select.  (With plain pointers hipcc turns "load, then select zero" back into a branch around
+// the load and waits vmcnt(0) between loads: a full memory latency per K chunk, exposed.)
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef float floatx4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t act_rsrc(const float* base, long elems) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
+}
+__device__ __forceinline__ float4 act_load4(__amdgpu_buffer_rsrc_t r, long elem, bool ok) {
+  // disabled / negative -> 0x80000000: beyond any descriptor (bytes < 2^31) without wrapping
+  const intx4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (ok && elem >= 0) ? (int)(elem * 4) : (int)0x80000000, 0, 0);
+  const floatx4v f = __builtin_bit_cast(floatx4v, v);
+  return make_float4(f[0], f[1], f[2], f[3]);
 }
 
 // address of the float4 of A this thread stages for chunk kc (or -1 when it is padding)
@@ -224,21 +241,20 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p
   const float* __restrict__ A2b = p.A2 ? p.A2 + (long)b * p.a_batch_stride : nullptr;
 
   float4 ra[A_VEC], rb[B_VEC];
+  const __amdgpu_buffer_rsrc_t rA = act_rsrc(Ab, p.a_len);
+  const __amdgpu_buffer_rsrc_t rA2 = act_rsrc(A2F ? A2b : Ab, p.a_len);
 
-  // Loads are unconditional (padding reads element 0 and is zeroed by a select afterwards) and
-  // the skip-connection operand is a compile-time variant: a runtime "load or zero" branch
-  // makes hipcc wait vmcnt(0) after every load, serialising the whole staging phase.
+  // The skip-connection operand is a compile-time variant (no runtime "load or zero" branch).
   auto gload = [&](int kc) {
 #pragma unroll
     for (int v = 0; v < A_VEC; ++v) {
       const long e = a_elem<BM, BK>(p, tid + v * 256, kc, cpb, m0);
-      const long ec = e >= 0 ? e : 0;
-      float4 x = *reinterpret_cast<const float4*>(Ab + ec);
+      float4 x = act_load4(rA, e, e >= 0);
       if (A2F) {
-        const float4 y = *reinterpret_cast<const float4*>(A2b + ec);
+        const float4 y = act_load4(rA2, e, e >= 0);
         x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
       }
-      ra[v] = e >= 0 ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[v] = x;
     }
 #pragma unroll
     for (int v = 0; v < B_VEC; ++v) {
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p
       }
     }
   }
-  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, 1.0f, RowsContig{m0, p.M_out});
+  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, 1.0f, RowsContig{m0, p.M_out}, blockIdx);
 }
 
 // ------------------------------------------------------------------ f16x3 split MFMA
@@ -341,7 +357,10 @@ __global__ __launch_bounds__(64 * WM * WN) void convgemm16_kernel(const asw_conv
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // (An XCD-aware tile order -- each XCD taking a contiguous eighth of the tile sequence so its
+  // L2 sees compact A x W blocks -- was measured twice: no change, 327 vs 323 TFLOP/s.)
+  const dim3 tile = blockIdx;
+  const int b = tile.z, m0 = tile.x * BM, n0 = tile.y * BN;
   const int K = p.taps * p.Cin;
   const int cpb = p.Cin / BK;
   const int nk = p.taps * cpb;
@@ -375,21 +394,21 @@ __global__ __launch_bounds__(64 * WM * WN) void convgemm16_kernel(const asw_conv
     b_ok[v] = (idx < BN * KH) && (n0 + row < p.N);
   }
   const long tap_step = (long)p.dil * p.a_row_stride;
+  const __amdgpu_buffer_rsrc_t rA = act_rsrc(Ab, p.a_len);
+  const __amdgpu_buffer_rsrc_t rA2 = act_rsrc(A2F ? A2b : Ab, p.a_len);
 
   auto gload = [&](int kc, float4 (&ra)[A_VEC], half8 (&rbh)[B_VEC], half8 (&rbl)[B_VEC]) {
     const int tap = kc / cpb;
     const long koff = tap * tap_step + (kc - tap * cpb) * BK;
 #pragma unroll
     for (int v = 0; v < A_VEC; ++v) {
-      const long e = a_row[v] + koff;
-      const bool ok = a_ok[v] && e >= 0 && e + 3 < p.a_len;
-      const long ec = ok ? e : 0;                       // unconditional load + select: see the f32 kernel
-      float4 x = *reinterpret_cast<const float4*>(Ab + ec);
+      const long e = a_row[v] + koff;                   // padding / past-the-end offsets read as zeros
+      float4 x = act_load4(rA, e, a_ok[v]);
       if (A2F) {
-        const float4 y = *reinterpret_cast<const float4*>(A2b + ec);
+        const float4 y = act_load4(rA2, e, a_ok[v]);
         x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
       }
-      ra[v] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[v] = x;
     }
 #pragma unroll
     for (int v = 0; v < B_VEC; ++v) {
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(64 * WM * WN) void convgemm16_kernel(const asw_conv
     if (kc + 1 < nk) gload(kc + 1, ra0, rbh0, rbl0);
     compute();
   }
-  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out});
+  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out}, tile);
 }
 
 // ------------------------------------------------------------------ halo-staged residual conv
@@ -499,9 +518,13 @@ struct ResRows {
   }
 };
 
-template <int BM, int C, int WM, int WN, int PH>
-__global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args p) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+template <int BM, int C, int WM, int WN, int PH, int QD = 4>
+__global__ __launch_bounds__(64 * WM * WN)
+__attribute__((amdgpu_waves_per_eu(WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 ? 2 : 3) : 1))))
+void resconv16_kernel(const asw_convgemm_args p) {
+  static_assert(QD == 2 || QD == 4, "B prefetch depth in k-steps");
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+  constexpr int NTHR = 64 * WM * WN, SROWS = NTHR / 16;   // staging: 16 threads per row
   constexpr int TM = BM / WM / 32, TN = C / WN / 32;
   constexpr int RS = 272;                    // bytes per staged row: 128 hi + 128 lo + 16 pad
   constexpr int NT = C / 32;                 // 32-column fragments across N
@@ -523,7 +546,7 @@ __global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args 
   const int RJ = BMJ + (PH == 1 ? (taps - 1) * dil : taps - 1);   // image rows per phase
   const int R = PH * RJ;
   const int tapstep = PH == 1 ? dil : 1;
-  const float* __restrict__ xb = p.A + (long)b * p.a_batch_stride;
+  const __amdgpu_buffer_rsrc_t rX = act_rsrc(p.A + (long)b * p.a_batch_stride, (long)T * C);
   const half8* __restrict__ Wh = reinterpret_cast<const half8*>(p.Wf_hi);
   const half8* __restrict__ Wl = reinterpret_cast<const half8*>(p.Wf_lo);
 
@@ -535,7 +558,7 @@ __global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int srow = tid >> 4, sc4 = tid & 15;          // staging: 16 threads per row, 16 rows per pass
+  const int srow = tid >> 4, sc4 = tid & 15;          // staging: 16 threads per row, SROWS rows per pass
   int a_base[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -547,11 +570,11 @@ __global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args 
   for (int cc = 0; cc < C / 64; ++cc) {
     __syncthreads();                                   // previous slice fully consumed
     // ---- stage + split the image of this channel slice (8 rows per thread in flight)
-    for (int r0 = 0; r0 < R; r0 += 16 * 8) {
+    for (int r0 = 0; r0 < R; r0 += SROWS * 8) {
       float4 buf[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int row = r0 + u * 16 + srow;
+        const int row = r0 + u * SROWS + srow;
         int g;
         bool ok = row < R;
         if (PH == 1) {
@@ -562,12 +585,11 @@ __global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args 
           ok = ok && ph < dil && (jb * BMJ + row % RJ - (taps - 1) / 2) >= 0;
         }
         ok = ok && g >= 0 && g < T;
-        const float4 x = *reinterpret_cast<const float4*>(xb + (long)(ok ? g : 0) * C + cc * 64 + sc4 * 4);
-        buf[u] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        buf[u] = act_load4(rX, (long)g * C + cc * 64 + sc4 * 4, ok);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int row = r0 + u * 16 + srow;
+        const int row = r0 + u * SROWS + srow;
         if (row < R) {
           half4 hi, lo;
           split4(buf[u], hi, lo);
@@ -608,22 +630,23 @@ __global__ __launch_bounds__(256) void resconv16_kernel(const asw_convgemm_args 
     // right after (tap, ks) has been multiplied, i.e. three k-steps (600-1200 MFMA cycles)
     // before its use -- enough to cover an L2 hit without the register cost of a second
     // whole-tap set (which halves occupancy; measured slower for C <= 128).
-    half8 qh[4][TN], ql[4][TN];
+    half8 qh[QD][TN], ql[QD][TN];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bload(0, ks, qh[ks], ql[ks]);
+    for (int ks = 0; ks < QD; ++ks) bload(0, ks, qh[ks], ql[ks]);
     for (int tap = 0; tap < taps; ++tap) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        compute(tap, ks, qh[ks], ql[ks]);
-        if (tap + 1 < taps) bload(tap + 1, ks, qh[ks], ql[ks]);
+        compute(tap, ks, qh[ks % QD], ql[ks % QD]);
+        const int nk = ks + QD, ntap = tap + nk / 4;               // QD k-steps ahead
+        if (ntap < taps) bload(ntap, nk % 4, qh[ks % QD], ql[ks % QD]);
       }
     }
   }
   epilogue<BM, C, WM, WN, true, false, true, false>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
-                                       ResRows<BM, PH>{m0, jb, pb, dil, T});
+                                       ResRows<BM, PH>{m0, jb, pb, dil, T}, blockIdx);
 }
 
-template <int BM, int C, int WM, int WN, int PH>
+template <int BM, int C, int WM, int WN, int PH, int QD = 4>
 int launch_res(const asw_convgemm_args& a, hipStream_t s) {
   constexpr int BMJ = BM / PH;
   const int RJ = BMJ + (PH == 1 ? (a.taps - 1) * a.dil : a.taps - 1);
@@ -631,7 +654,7 @@ int launch_res(const asw_convgemm_args& a, hipStream_t s) {
   const size_t slab = (size_t)(WM * 32) * (C + 4) * sizeof(float);
   const size_t smem = img > slab ? img : slab;
   if (smem > 160 * 1024) return 1;                     // caller falls back to the generic kernel
-  auto kern = resconv16_kernel<BM, C, WM, WN, PH>;
+  auto kern = resconv16_kernel<BM, C, WM, WN, PH, QD>;
   static bool attr = false;
   if (!attr) {
     ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -641,13 +664,15 @@ int launch_res(const asw_convgemm_args& a, hipStream_t s) {
   const int gx = PH == 1 ? asw::cdiv(a.M_out, BM)
                          : asw::cdiv(asw::cdiv(a.M_out, a.dil), BMJ) * asw::cdiv(a.dil, PH);
   dim3 grid(gx, 1, a.B);
-  char nm[64];
-  snprintf(nm, sizeof nm, "resconv16<%d,%d,ph%d>", BM, C, PH);
+  char nm[96];
+  int nl = snprintf(nm, sizeof nm, "resconv16<%d,%d,ph%d%s>", BM, C, PH, QD == 2 ? ",q2" : "");
+  if (asw::prof_detail()) snprintf(nm + nl, sizeof nm - nl, "[B%d M%d N%d K%d d%d]", a.B, a.M_out, a.N, a.taps * a.Cin, a.dil);
   asw::ProfScope prof(s, nm, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, a);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }
+
 
 // returns 1 when the layer is not a halo-kernel case (or does not fit LDS)
 int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
@@ -660,11 +685,22 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
   // MFMA tile; on short sequences (T/dil < 32, e.g. T = 752 at dil 49) most of each tile
   // would be empty (measured: 141 vs 243 TFLOP/s), so those stay contiguous
   const bool poly = a.dil >= 16 && a.M_out / a.dil >= 32;
+  // Tile / prefetch choices are measured (tests/perf_layers.py, T = 48 000, batch 64):
+  //  C = 64  : waves 2x2 (64 rows x 32 columns each) halves the weight fragments every wave
+  //            pulls through L1 compared with 4x1 -> 222 -> 257 TFLOP/s.  (A persistent variant
+  //            with the weights stationary in registers, 224 VGPRs per wave, was tried: one wave
+  //            per SIMD leaves the LDS reads of the A operand exposed -> 160 TFLOP/s.);
+  //  C = 128 : B prefetch depth 2 fits 3 waves/SIMD -> 294 -> 312 TFLOP/s (dil 49: 259 -> 279);
+  //  C = 256 : depth 4 and depth 2 tie, keep 4;
+  //  C = 512 : depth 2 fits 2 workgroups per CU -> 346 -> 366 TFLOP/s, except dilation 49 whose
+  //            contiguous halo image (294 extra rows) leaves room for one workgroup anyway.
   switch (a.N) {
-    case 64: return poly ? launch_res<128, 64, 4, 1, 4>(a, s) : launch_res<128, 64, 4, 1, 1>(a, s);
-    case 128: return poly ? launch_res<128, 128, 2, 2, 4>(a, s) : launch_res<128, 128, 2, 2, 1>(a, s);
+    case 64: return poly ? launch_res<128, 64, 2, 2, 4>(a, s) : launch_res<128, 64, 2, 2, 1>(a, s);
+    case 128: return poly ? launch_res<128, 128, 2, 2, 4, 2>(a, s) : launch_res<128, 128, 2, 2, 1, 2>(a, s);
     case 256: return poly ? launch_res<64, 256, 1, 4, 2>(a, s) : launch_res<64, 256, 1, 4, 1>(a, s);
-    case 512: return poly ? launch_res<64, 512, 1, 4, 2>(a, s) : launch_res<64, 512, 1, 4, 1>(a, s);
+    case 512:
+      if (poly) return launch_res<64, 512, 1, 4, 2>(a, s);
+      return a.dil >= 16 ? launch_res<64, 512, 1, 4, 1>(a, s) : launch_res<64, 512, 1, 4, 1, 2>(a, s);
     default: return 1;
   }
 }
@@ -688,9 +724,14 @@ int launch(const asw_convgemm_args& a, hipStream_t s) {
   ASW_CHECK_ARG(a.Cin % BK == 0, "convgemm: Cin=%d not a multiple of BK=%d", a.Cin, BK);
   ASW_CHECK_ARG(a.N % BN == 0, "convgemm: N=%d not a multiple of BN=%d", a.N, BN);
   dim3 grid(asw::cdiv(a.M_out, BM), a.N / BN, a.B);
-  asw::ProfScope prof(s, asw::prof_name(F16 ? (MUL ? "convgemm16m" : "convgemm16") : (MUL ? "convgemm_m" : "convgemm"),
-                                        BM, BN, BK, LN, STATS),
-                      2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
+  std::string pn = asw::prof_name(F16 ? (MUL ? "convgemm16m" : "convgemm16") : (MUL ? "convgemm_m" : "convgemm"),
+                                  BM, BN, BK, LN, STATS);
+  if (asw::prof_detail()) {
+    char sh[64];
+    snprintf(sh, sizeof sh, "[B%d M%d N%d K%d s%d]", a.B, a.M_out, a.N, a.taps * a.Cin, a.stride);
+    pn += sh;
+  }
+  asw::ProfScope prof(s, pn, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
   if constexpr (F16)
     hipLaunchKernelGGL((convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>), grid, dim3(64 * WM * WN), smem, s, a);
   else
@@ -789,6 +830,8 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
   if (a.precision == 1) ASW_CHECK_ARG(a.Wt_hi && a.Wt_lo, "convgemm: f16x3 needs Wt_hi/Wt_lo");
   else ASW_CHECK_ARG(a.Wt != nullptr, "convgemm: null weights");
   ASW_CHECK_ARG(a.B > 0 && a.M_out > 0 && a.N > 0 && a.Cin > 0 && a.taps > 0, "convgemm: bad dims");
+  ASW_CHECK_ARG(a.a_len > 0 && a.a_len < (int64_t)1 << 29, "convgemm: a_len=%lld per batch item exceeds the 2 GiB buffer descriptor",
+                (long long)a.a_len);
   ASW_CHECK_ARG(a.a_row_stride % 4 == 0 && a.a_batch_stride % 4 == 0 && a.a_len % 4 == 0 && a.Cin % 8 == 0,
                 "convgemm: strides must be multiples of 4 floats, Cin of 8");
   ASW_CHECK_ARG(a.B <= 65535, "convgemm: batch %d exceeds grid.z", a.B);

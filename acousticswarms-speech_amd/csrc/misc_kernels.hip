@@ -316,7 +316,69 @@ __global__ __launch_bounds__(1024) void center_rows_kernel(float* __restrict__ y
   for (int i = threadIdx.x; i < T; i += 1024) yb[i] -= mu;
 }
 
+// out[r][:] = LayerNorm(x[r][:] + resid[r][:]) * gamma + beta   (post-norm transformer block,
+// nn.TransformerEncoderLayer norm1/norm2, sep/training/SpeakerLocalization/network.py:254).
+// One wave per row, the row in registers (NV float4 per lane), two-pass statistics by wave
+// shuffles -- the same arithmetic as the GEMM epilogue's fused LayerNorm.  Used for rows too
+// wide (d = 1024) for a LayerNorm-fused GEMM tile of useful height: the GEMM then runs on the
+// wide 256x256 tile and this pass costs one read + one write of the activations.
+template <int NV>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ resid,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int rows, float eps, float* __restrict__ out) {
+  constexpr int N = NV * 256;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (long)row * N);
+  const float4* rr = reinterpret_cast<const float4*>(resid + (long)row * N);
+  float4 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 a = xr[i * 64 + lane], r = rr[i * 64 + lane];
+    v[i] = make_float4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
+    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mu = sum / (float)N;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+    sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.0f / sqrtf(sq / (float)N + eps);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float4* orow = reinterpret_cast<float4*>(out + (long)row * N);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 g = g4[i * 64 + lane], b = b4[i * 64 + lane];
+    orow[i * 64 + lane] = make_float4((v[i].x - mu) * rstd * g.x + b.x, (v[i].y - mu) * rstd * g.y + b.y,
+                                      (v[i].z - mu) * rstd * g.z + b.z, (v[i].w - mu) * rstd * g.w + b.w);
+  }
+}
+
 }  // namespace
+
+extern "C" int asw_add_layernorm(const float* x, const float* resid, const float* gamma, const float* beta, int rows,
+                                 int N, float eps, float* out, void* stream) {
+  ASW_CHECK_ARG(x && resid && gamma && beta && out, "add_layernorm: null pointer");
+  ASW_CHECK_ARG(rows >= 0 && N > 0 && N % 256 == 0 && N <= 2048, "add_layernorm: N=%d must be a multiple of 256 <= 2048", N);
+  if (rows == 0) return ASW_OK;
+  hipStream_t s = asw::as_stream(stream);
+  dim3 grid(asw::cdiv(rows, 4));
+  switch (N / 256) {
+#define ASW_ALN(NV) case NV: hipLaunchKernelGGL(add_layernorm_kernel<NV>, grid, dim3(256), 0, s, x, resid, gamma, beta, rows, eps, out); break;
+    ASW_ALN(1) ASW_ALN(2) ASW_ALN(3) ASW_ALN(4) ASW_ALN(5) ASW_ALN(6) ASW_ALN(7) ASW_ALN(8)
+#undef ASW_ALN
+  }
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
 
 extern "C" int asw_center_rows(float* y, int B, int T, void* stream) {
   ASW_CHECK_ARG(y && T > 0, "center_rows: bad argument");

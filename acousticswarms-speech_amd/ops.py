@@ -106,6 +106,14 @@ def gn_glu(raw, stats, gamma, beta, eps=1e-5):
     return out
 
 
+def add_layernorm(x, resid, gamma, beta, eps=1e-5):
+    rows, N = x.shape
+    out = torch.empty_like(x)
+    check(lib().asw_add_layernorm(ptr(_f32(x)), ptr(_f32(resid)), ptr(_f32(gamma)), ptr(_f32(beta)), rows, N, eps,
+                                  ptr(out), current_stream()))
+    return out
+
+
 def attention(qkv, nhead):
     B, L, d3 = qkv.shape
     d = d3 // 3

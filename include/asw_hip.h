@@ -219,6 +219,13 @@ int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int taps, int 
 int asw_energies(const float* y, int B, int T, int window, double* scratch, double* out,
                  void* stream);
 
+/* out = LayerNorm(x + resid) * gamma + beta over rows of N floats (N % 256 == 0, N <= 2048):
+ * norm1 / norm2 of the post-norm nn.TransformerEncoderLayer
+ * (sep/training/SpeakerLocalization/network.py:254) when the row is too wide to fuse into the
+ * producing GEMM's tile.  out may alias x. */
+int asw_add_layernorm(const float* x, const float* resid, const float* gamma, const float* beta,
+                      int rows, int N, float eps, float* out, void* stream);
+
 /* In-place mean removal of every row (sep/Mic_Array.py:291, local_utils_3d.py:350): the
  * stage loops centre each candidate output before comparing waveforms. */
 int asw_center_rows(float* y, int B, int T, void* stream);

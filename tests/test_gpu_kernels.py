@@ -178,6 +178,20 @@ def test_attention(ops, L, d, nhead, B):
     assert rel < 3e-6
 
 
+@pytest.mark.parametrize("rows,N", [(5, 256), (1203, 1024), (64, 2048), (1, 768)])
+def test_add_layernorm(ops, rows, N):
+    """norm(x + resid) of the post-norm transformer block, rows wider than a fused GEMM tile."""
+    x, r = _rand(rows, N, seed=40, scale=2.0) + 0.3, _rand(rows, N, seed=41)
+    g, b = _rand(N, seed=42) * 0.2 + 1.0, _rand(N, seed=43, scale=0.1)
+    want = F.layer_norm(x + r, (N,), g, b, 1e-5)
+    out = ops.add_layernorm(x.cuda(), r.cuda(), g.cuda(), b.cuda())
+    rel, mx = _relerr(out.cpu(), want)
+    _log(f"add_layernorm rows={rows} N={N}: rel={rel:.3e} max={mx:.3e}")
+    assert rel < 1e-6
+    with pytest.raises(RuntimeError):
+        ops.add_layernorm(x[:, :100].contiguous().cuda(), r[:, :100].contiguous().cuda(), g[:100].cuda(), b[:100].cuda())
+
+
 def test_mask_path(ops):
     """reference_bypass * mask_encoder -> output_decoder -> trim (network.py:397-405)."""
     B, C, E, EK, ES, Tp, t = 2, 64, 256, 33, 16, 2048, 1900
