@@ -674,6 +674,7 @@ int launch_res(const asw_convgemm_args& a, hipStream_t s) {
 }
 
 
+
 // returns 1 when the layer is not a halo-kernel case (or does not fit LDS)
 int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
   const bool shape = a.precision == 1 && a.Wf_hi && a.Wf_lo && a.ln_gamma && a.stride == 1 && a.taps > 1 &&
@@ -694,6 +695,11 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
   //  C = 256 : depth 4 and depth 2 tie, keep 4;
   //  C = 512 : depth 2 fits 2 workgroups per CU -> 346 -> 366 TFLOP/s, except dilation 49 whose
   //            contiguous halo image (294 extra rows) leaves room for one workgroup anyway.
+  // Also measured and dropped: 8-wave 128-row tiles for C >= 256 (305 vs 368), and a persistent
+  // variant that double-buffers the image slices (prefetch under the MFMAs, one barrier per
+  // slice): 338 vs 330 at C = 256 but 146 vs 239 where the doubled image costs a resident
+  // workgroup.  With the epilogue removed the same loops run at 355-385 TFLOP/s, the level of an
+  // idealised k-step loop fed from L2 on random data (tests/micro/cu_probe.hip: 400).
   switch (a.N) {
     case 64: return poly ? launch_res<128, 64, 2, 2, 4>(a, s) : launch_res<128, 64, 2, 2, 1>(a, s);
     case 128: return poly ? launch_res<128, 128, 2, 2, 4, 2>(a, s) : launch_res<128, 128, 2, 2, 1, 2>(a, s);

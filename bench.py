@@ -28,6 +28,11 @@ import torch  # noqa: E402
 # f16x3 mode every algorithmic product costs three f16 MFMAs, so the ceiling for ALGORITHMIC
 # flops is 2500 / 3.
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3.0}
+# What the matrix pipe sustains on this chip with random (non-zero) fp16 operands and nothing else
+# running: 1.63 PFLOP/s of v_mfma_f32_32x32x16_f16 (2.2 with all-zero operands), i.e. the clock is
+# power-limited under dense MFMA load (tests/micro/cu_probe.hip, profiles/r1/cu_probe_random_operands.txt).
+# Reported beside the nominal peak; `frac` stays on the nominal figure.
+SUSTAINED_TFLOPS = {"f16x3": 1630.0 / 3.0}
 DTYPE_NAME = {"f32": "f32", "f16x3": "f32 via f16x3 split-operand MFMA (fp32 accumulate)"}
 
 
@@ -192,6 +197,11 @@ def main():
                 pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "sustained_peak": ({"tflops": round(SUSTAINED_TFLOPS[args.precision], 1),
+                                        "frac": round(ach / SUSTAINED_TFLOPS[args.precision], 4),
+                                        "note": "MFMA-only loop on random operands, power-limited clock; "
+                                                "profiles/r1/cu_probe_random_operands.txt"}
+                                       if args.precision in SUSTAINED_TFLOPS else None),
                     "avg_launch_ms": round(rec["ms"] / rec["launches"], 4), "launches": rec["launches"],
                     "all_gemm_kernels": {"achieved": round(tot_work / (tot_ms * 1e-3) / 1e12, 2),
                                          "frac": round(tot_work / (tot_ms * 1e-3) / 1e12 / peak, 4),
