@@ -123,3 +123,53 @@ def test_fine_stage_device_resident_equals_host_path(mic_array, golden):
         np.testing.assert_array_equal(pa[4]["audio_offset"], pb[4]["audio_offset"])
         np.testing.assert_allclose(pa[4]["localization_offset"], pb[4]["localization_offset"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(pa[1], pb[1], rtol=0, atol=1e-6 * max(1.0, np.abs(pb[1]).max()))
+
+
+def test_search_hip_vs_oracle_north_star_tolerance(mic_array):
+    """The north-star tolerance, end to end: the complete search (SRP-PHAT -> coarse -> fine ->
+    clustering) run twice on the same mixture with the same seeded FULL weights -- once with the
+    HIP spot model in its default f16x3 arithmetic, once with the CPU oracle behind the
+    reference's shift_and_sep surface -- must pick the same talkers, place them within 2 cm
+    and return waveforms whose SI-SDR against the oracle's is far beyond the 0.1 dB budget
+    (>= 60 dB, i.e. a 1e-6 relative perturbation of any SI-SDR computed from them)."""
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.hostdsp import si_sdr
+    from acousticswarms_speech_amd.joint import JointModel
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    from oracle import spot_ref
+    ma, mics, spk, mix = mic_array
+    sd = make_spot_state_dict(FULL, 5)
+    T = 24000
+    mix_t = torch.from_numpy(mix[:, :T].copy())
+
+    class OracleSpot:                      # the reference surface, computed by oracle/spot_ref.py on the CPU
+        def __init__(self):
+            self.calls = []
+
+        def shift_and_sep(self, m, patch_list, Strict=0, save_input=False):
+            self.calls.append((len(patch_list), Strict))
+            if len(patch_list) == 0:
+                return np.empty((0, m.shape[1]), dtype=np.float32)
+            return spot_ref.shift_and_sep(sd, FULL, m, [p.sample_offset for p in patch_list], strict=Strict,
+                                          batch_size=8)
+
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    res = {}
+    for name, spot in (("hip", SpotModel(FULL, sd, batch_size=32, precision="f16x3").to("cuda")),
+                       ("oracle", OracleSpot())):
+        jm = JointModel(spot, None, device="cuda")
+        with redirect_stdout(io.StringIO()):
+            jm.setup(mics, ROI)
+            patches, audio_loc, _audio, _, _, spot_times = jm.forward(mix_t)
+        res[name] = (patches, audio_loc, spot_times, list(jm.times))
+    (ph, ah, nh, th), (po, ao, no, to) = res["hip"], res["oracle"]
+    _log(f"north-star: talkers hip={len(ph)} oracle={len(po)}, spot calls {nh}/{no}, "
+         f"stage s hip={np.round(th, 3)} oracle={np.round(to, 1)}")
+    assert nh == no and len(ph) == len(po) and len(ph) >= 1
+    assert [p[3] for p in ph] == [p[3] for p in po]                     # same candidates survive, same order
+    err_cm = [100 * float(np.linalg.norm(a[0].center_pos() - b[0].center_pos())) for a, b in zip(ph, po)]
+    sdr = [si_sdr(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)) for a, b in zip(ah, ao)]
+    _log(f"north-star: position error cm {np.round(err_cm, 4)}, SI-SDR(hip, oracle) dB {np.round(sdr, 1)}")
+    assert max(err_cm) <= 2.0
+    assert min(sdr) >= 60.0
