@@ -213,7 +213,7 @@ def main():
         if not args.no_e2e:
             e2e = e2e_latency(model, scene, dev)
         cpu = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:           # reported on rank 0 at N = 1 only
             cpu = cpu_baseline(cfg, sd, torch.from_numpy(scene.mix), offsets, args.cpu_sample)
         line = {
             "metric": "TDoA candidates/sec (shift+normalise+spot forward+energies)", "value": round(value, 2),
