@@ -39,9 +39,22 @@ class GridCluster(object):
 
 def _offsets_within(offsets, center, width):
     """All pairs within +-width/2 of ``center`` (hyperbola_offset / hyperbola_area_sample,
-    SRP_Prunning.py:19-39); offsets [..., P]."""
+    SRP_Prunning.py:19-39); offsets [..., P].  The same comparisons as the all-pairs mask,
+    evaluated pair by pair on the survivors only (the cube is a tiny part of the table)."""
     c = np.asarray(center, dtype=np.float64)
-    return np.all((offsets >= c - width / 2) & (offsets <= c + width / 2), axis=-1)
+    lo, hi = c - width / 2, c + width / 2
+    P = offsets.shape[-1]
+    flat = offsets.reshape(-1, P)
+    v = flat[:, 0]
+    idx = np.flatnonzero((v >= lo[0]) & (v <= hi[0]))
+    for p in range(1, P):
+        if idx.shape[0] == 0:
+            break
+        v = flat[idx, p]
+        idx = idx[(v >= lo[p]) & (v <= hi[p])]
+    mask = np.zeros(flat.shape[0], dtype=bool)
+    mask[idx] = True
+    return mask.reshape(offsets.shape[:-1])
 
 
 class SRPPhat(object):
