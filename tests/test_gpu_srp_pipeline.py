@@ -173,3 +173,88 @@ def test_search_hip_vs_oracle_north_star_tolerance(mic_array):
     _log(f"north-star: position error cm {np.round(err_cm, 4)}, SI-SDR(hip, oracle) dB {np.round(sdr, 1)}")
     assert max(err_cm) <= 2.0
     assert min(sdr) >= 60.0
+
+
+# ---------------------------------------------------------------- two ranks, real HIP model
+def _sharded_hip_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from acousticswarms_speech_amd.config import FULL
+        from acousticswarms_speech_amd.mic_array import MicArray
+        from acousticswarms_speech_amd.shard import ShardedSpotModel
+        from acousticswarms_speech_amd.spot import SpotModel
+        from acousticswarms_speech_amd.weights import make_spot_state_dict
+        mics, _spk, mix = scene_in_roi()
+        inner = SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=32, precision="f16x3").to("cuda")
+        spot = ShardedSpotModel(inner, device="cpu")          # both ranks share the one GPU here: gloo carries the collectives
+        evaluated = []
+        orig = inner.shift_and_sep_device
+
+        def counting(mix_d, offs, *a, **kw):
+            evaluated.append(int(offs.shape[0]))
+            return orig(mix_d, offs, *a, **kw)
+        inner.shift_and_sep_device = counting
+        with redirect_stdout(io.StringIO()):
+            ma = MicArray(mics, Spk_Range=ROI, device="cuda")
+            mix_t = torch.from_numpy(mix[:, :24000].copy())
+            p1, _ = ma.Apply_SRP_PHAT(mix_t)
+            p2 = ma.Spotform_Big_Patch(mix_t, p1, spot)
+            pairs = ma.Spotform_Small_Patch_Parallel(mix_t, p2, spot)
+            _audio, final, spot_times, _ = ma.Clustering_new(pairs) if len(pairs) else ([], [], 0, None)
+        q.put((rank, len(p2), [p[3] for p in pairs], np.array([p[2] for p in pairs]),
+               np.array([p[0].center_pos() for p in pairs]), [p[3] for p in final], spot_times, sum(evaluated),
+               None if not hasattr(ma, "fine_energies") else ma.fine_energies))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_search_with_hip_model(mic_array):
+    """The multi-GPU search path with the real HIP model: two ranks (sharing the one GPU of this
+    box, collectives over gloo) shard the coarse candidates and the fine-stage groups, all-gather
+    energies and output tuples, and must end with the same output as one process."""
+    import socket
+    import torch.multiprocessing as mp
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.mic_array import MicArray
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    mics, _spk, mix = scene_in_roi()
+    spot = SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=32, precision="f16x3").to("cuda")
+    with redirect_stdout(io.StringIO()):
+        ma = MicArray(mics, Spk_Range=ROI, device="cuda")
+        mix_t = torch.from_numpy(mix[:, :24000].copy())
+        p1, _ = ma.Apply_SRP_PHAT(mix_t)
+        p2 = ma.Spotform_Big_Patch(mix_t, p1, spot)
+        pairs = ma.Spotform_Small_Patch_Parallel(mix_t, p2, spot)
+        _a, final, spot_times, _ = ma.Clustering_new(pairs)
+    want = (len(p2), [p[3] for p in pairs], np.array([p[2] for p in pairs]),
+            np.array([p[0].center_pos() for p in pairs]), [p[3] for p in final], spot_times)
+    del spot
+    torch.cuda.empty_cache()
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_hip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    total_eval = 0
+    for rank, n2, names, power, centre, fnames, st, n_eval, fine_en in res:
+        assert n2 == want[0] and names == want[1] and fnames == want[4] and st == want[5]
+        np.testing.assert_allclose(power, want[2], rtol=1e-5)
+        np.testing.assert_allclose(centre, want[3], atol=1e-9)
+        assert fine_en is not None and fine_en.ndim == 2 and fine_en.shape[1] == 2
+        total_eval += n_eval
+    np.testing.assert_array_equal(res[0][8], res[1][8])                  # every rank holds every fine energy
+    _log(f"two-rank sharded search: pairs {len(want[1])}, final {len(want[4])}, candidates evaluated per rank "
+         f"{[r[7] for r in res]} of {want[5]}")
+    assert total_eval == want[5]                                        # each candidate evaluated exactly once
