@@ -46,3 +46,11 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("expected RuntimeError")
+
+
+def test_header_is_plain_c():
+    """include/asw_hip.h must be consumable from C (cgo / JNI / ctypes-style bindings)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror",
+                    os.path.join(root, "include", "asw_hip.h")], check=True)

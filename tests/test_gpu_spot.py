@@ -191,3 +191,47 @@ def test_sixteen_mic_dense_candidates_vs_oracle():
         assert min(per) > 80.0
         en = m.shift_and_score(mix, pick, Strict=strict, window=1500)
         np.testing.assert_allclose(en, spot_ref.candidate_energies(ref, 1500), rtol=1e-4)
+
+
+@pytest.mark.parametrize("T", [48000, 144000])
+def test_full_size_properties(T):
+    """BASELINE.json's full sizes (FULL net, 7 mics, T = 48 000 and the reference-native 144 000),
+    where the oracle is too slow to be the checker: size-independent properties of the hot call.
+      * the internal batching is invisible: 13 candidates scored in batches of 5 and in one batch
+        agree to 1e-6 (not bit for bit: the GEMM tile shape follows the grid size and the
+        GroupNorm partial sums follow the tiles);
+      * a permuted candidate list gives the permuted result, bit for bit;
+      * the energies of the fast path equal the energies recomputed from the returned waveforms
+        (mean removal, sum of squares, max windowed RMS: local_utils_3d.py:13-17,349-354);
+      * a candidate scored twice in one internal batch gives the same bits (no cross-candidate
+        state)."""
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.scenes import make_scene, random_offsets
+    from oracle import spot_ref
+    m = _model(FULL, 5, batch=5)
+    m.set_precision("f16x3")
+    mix = torch.from_numpy(make_scene(1001, 3, 7, T).mix)
+    offs = random_offsets(3, 12, 6, 140)
+    offs = np.concatenate([offs, offs[:1]])                    # 13 candidates
+    offs[4] = offs[0]                                          # a repeat inside the first internal batch
+
+    class P:
+        def __init__(self, o):
+            self.sample_offset = o
+    patches = [P(o) for o in offs]
+    en5 = m.shift_and_score(mix, patches, Strict=1, keep_waveforms=True)
+    waves = m.last_waveforms.cpu().numpy()
+    assert waves.shape == (13, T) and np.isfinite(waves).all()
+    np.testing.assert_array_equal(en5[0], en5[4])
+    np.testing.assert_array_equal(waves[0], waves[4])
+    np.testing.assert_allclose(en5[0], en5[12], rtol=1e-6)     # same candidate in a batch of 3
+    m.set_batch_size(13)
+    en13 = m.shift_and_score(mix, patches, Strict=1)
+    np.testing.assert_allclose(en5, en13, rtol=1e-6)
+    perm = np.random.default_rng(0).permutation(13)
+    enp = m.shift_and_score(mix, [patches[i] for i in perm], Strict=1)
+    np.testing.assert_array_equal(enp, en13[perm])
+    np.testing.assert_allclose(en13, spot_ref.candidate_energies(waves, 12000), rtol=1e-4)
+    # the two window embeddings are different networks (gates folded into the weights)
+    en_relaxed = m.shift_and_score(mix, patches[:3], Strict=0)
+    assert not np.array_equal(en_relaxed, en13[:3])
