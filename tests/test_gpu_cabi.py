@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_cabi_harness_runs_without_python():
     from acousticswarms_speech_amd import native
-    native.build()
+    native.lib()                       # the prebuilt in-tree library (never rebuilt under a running process)
     pkg = os.path.dirname(native.LIB_PATH)
     exe = os.path.join(ROOT, "tests", "cabi", "cabi_harness")
     subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cabi", "cabi_harness.cpp"),
