@@ -9,7 +9,7 @@ import numpy as np
 
 from . import search
 from .hostdsp import max_avg_power, si_sdr, split_wav, split_wise_sisdr
-from .patch import FS, SPEED_OF_SOUND, Patch
+from .patch import FS, SPEED_OF_SOUND, Patch, pair_offsets
 from .search import (INIT_WIDTH, SPOT_POWER_THRESHOLD2, USE_RELATIVE_SPOT_POWER, binary_search_baseline,
                      search_area)
 from .srp import SRPPhat
@@ -42,18 +42,20 @@ def weight_mean_pos(patch_list, powers, id_lists):
     return pos / tot, offs / tot
 
 
-def find_merge_center(merged_offests, init_area, mic_positions, Big_patch_center):
+def find_merge_center(merged_offests, init_area, mic_positions, Big_patch_center, init_samples=None):
     """Patch of width 3 around the merged offsets holding the coarse patch's points that fall
     inside; falls back to the coarse centre (sep/Mic_Array.py:50-81).  The reference's
-    widening loop leaves after its first pass (factor 0), which repeats the width-3 test."""
+    widening loop leaves after its first pass (factor 0), which repeats the width-3 test.
+    ``init_samples`` may carry pair_offsets(init_area, mic_positions) when the caller tests many
+    cluster heads against the same coarse patch (same values, computed once)."""
     P = mic_positions.shape[0] - 1
     patch = Patch(merged_offests, [3 for _ in range(P)], None)
-    inside = patch.hyperbola_general_area(init_area[0, :], init_area[1, :], init_area[2, :], mic_positions,
-                                          SPEED_OF_SOUND, FS) == 1
+    if init_samples is None:
+        init_samples = pair_offsets(init_area, mic_positions, SPEED_OF_SOUND, FS)
+    inside = patch.hyperbola_sample(init_samples) == 1
     if np.sum(inside) == 0:
         patch.width_list = [3 for _ in range(P)]
-        inside = patch.hyperbola_general_area(init_area[0, :], init_area[1, :], init_area[2, :], mic_positions,
-                                              SPEED_OF_SOUND, FS) == 1
+        inside = patch.hyperbola_sample(init_samples) == 1
         if np.sum(inside) > 0:
             patch.area_points = init_area[:, inside]
         else:
@@ -213,9 +215,12 @@ class MicArray(object):
                 heads = list(clusters.keys())
                 head_audio = waves_dev[[bounds[i] + h for h in heads]].cpu().numpy()
                 audio_of = {h: head_audio[n] for n, h in enumerate(heads)}
+            area_samples = None
             for head in clusters:
                 _position, offs = weight_mean_pos(patches, powers, clusters[head])
-                centre = find_merge_center(offs, areas[g], self.mic_positions, centers[g])
+                if area_samples is None:                                    # once per coarse patch
+                    area_samples = pair_offsets(areas[g], self.mic_positions, SPEED_OF_SOUND, FS)
+                centre = find_merge_center(offs, areas[g], self.mic_positions, centers[g], area_samples)
                 if centre.center_pos() is None:
                     print("Warning some bug happen one source may be drop")
                 audio = audio_of[head] if resident else sep[head, :]
