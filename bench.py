@@ -187,16 +187,23 @@ def main():
             ach = rec["work"] / (rec["ms"] * 1e-3) / 1e12
             tot_ms = sum(r["ms"] for r in prof.values())
             tot_work = sum(r["work"] for r in prof.values())
-            traffic = None
+            traffic = traffic_detail = None
             try:      # measured offline by rocprofv3 --pmc (separate passes); only valid for the same kernel
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
                 if tj["kernel"] == name:
-                    traffic = {"read_bytes_per_launch_raw": tj["read_bytes_raw"], "write_bytes_per_launch": tj["write_bytes"],
-                               "algorithmic_bytes_per_launch": tj["algorithmic_bytes"], "source": "profiles/r1/traffic.json"}
+                    # per launch of the dominant kernel = one internal batch; counters were taken at batch tj["batch"]
+                    scale = min(args.batch, args.candidates) / float(tj["batch"])
+                    traffic = int(tj["corrected_bytes_per_launch"] * scale)
+                    traffic_detail = {"fetch_size_bytes_raw": int(tj["read_bytes_raw"] * scale),
+                                      "write_size_bytes": int(tj["write_bytes"] * scale),
+                                      "algorithmic_bytes": int(tj["algorithmic_bytes"] * scale),
+                                      "correction": "FETCH_SIZE x2 (gfx950 wide streaming reads) + WRITE_SIZE",
+                                      "counters_measured_at_batch": tj["batch"], "source": "profiles/r1/traffic.json"}
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "traffic_detail": traffic_detail,
                     "sustained_peak": ({"tflops": round(SUSTAINED_TFLOPS[args.precision], 1),
                                         "frac": round(ach / SUSTAINED_TFLOPS[args.precision], 4),
                                         "note": "MFMA-only loop on random operands, power-limited clock; "
