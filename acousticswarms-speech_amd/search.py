@@ -78,12 +78,11 @@ def search_area(patch_list, mic_positions, upper_bound_pairwise):
     """Breadth-first subdivision of ONE coarse patch into fine hypercubes
     (local_utils_3d.py:212-246): patch_list = [coarse_patch].  Runs in the native library
     (csrc/search_host.cpp, same float64 arithmetic, ~8x faster); ``search_area_py`` below is
-    the same algorithm in numpy and is used when the library has not been built."""
-    try:
-        from . import native
-        L = native.lib()
-    except (RuntimeError, OSError):
-        return search_area_py(patch_list, mic_positions, upper_bound_pairwise)
+    the same algorithm in numpy, kept as the readable statement the tests compare against.
+    Like every other entry of the path this one needs the built library (``native.lib()``
+    raises otherwise)."""
+    from . import native
+    L = native.lib()
     import ctypes
     from ctypes import byref, c_int, c_void_p
     root = patch_list[0]

@@ -21,3 +21,13 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The host search calls into libasw_hip.so (native hypercube subdivision), so even the CPU
+    suite needs the library: build it once when it is absent.  An existing library is never
+    rebuilt from inside a test session (it may already be mapped by this process)."""
+    from acousticswarms_speech_amd import native
+    if not os.path.exists(native.LIB_PATH):
+        native.build()
