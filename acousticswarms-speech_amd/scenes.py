@@ -83,9 +83,13 @@ def desk_mics(rng, n_mics=7):
 
 
 def make_scene(seed: int, n_speakers: int = 3, n_mics: int = 7, T: int = 48000,
-               fs: int = FS, reverb: bool = False, noise_std: float = 1e-3) -> Scene:
+               fs: int = FS, reverb: bool = False, noise_std: float = 1e-3, mic_positions=None) -> Scene:
+    """``mic_positions`` fixes the array geometry (several mixtures of one recording session);
+    by default every seed draws its own desk and robot positions."""
     rng = np.random.default_rng(1000 + seed if seed < 1000 else seed)
     mics, (dx, dy) = desk_mics(rng, n_mics)
+    if mic_positions is not None:
+        mics = np.asarray(mic_positions, dtype=np.float64)
     roi = [-2.2, 2.2, 0.3, 4.0, 0.1, 0.9]
     spk = []
     tries = 0

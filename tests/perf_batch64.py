@@ -1,0 +1,50 @@
+"""BASELINE config 4 on ONE GPU (the driver owns the 8-GPU node): 64 five-speaker mixtures
+(seeds 2000-2063), the complete search of each through shard.localize_batch -- which on N ranks
+deals whole mixtures to ranks and all-gathers the per-mixture results.  Prints mixtures/s,
+candidates/s inside the search and the stage split.  Diagnostic, not the headline bench."""
+import io
+import json
+import os
+import sys
+import time
+from contextlib import redirect_stdout
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from acousticswarms_speech_amd.config import FULL  # noqa: E402
+from acousticswarms_speech_amd.joint import JointModel  # noqa: E402
+from acousticswarms_speech_amd.scenes import make_scene  # noqa: E402
+from acousticswarms_speech_amd.shard import localize_batch  # noqa: E402
+from acousticswarms_speech_amd.spot import SpotModel  # noqa: E402
+from acousticswarms_speech_amd.weights import make_spot_state_dict  # noqa: E402
+
+
+def main(n_mix=64, T=48000):
+    model = SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=128, precision="f16x3").to("cuda")
+    jm = JointModel(model, None, device="cuda")
+    sc0 = make_scene(2000, 5, 7, T)
+    # one array geometry for the whole batch (a recording session): setup() once, excluded like the reference's
+    mixes = [torch.from_numpy(make_scene(2000 + i, 5, 7, T, mic_positions=sc0.mic_positions).mix) for i in range(n_mix)]
+    with redirect_stdout(io.StringIO()):
+        jm.setup(sc0.mic_positions, sc0.speaker_range)
+        jm.forward(mixes[0])                                       # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with redirect_stdout(io.StringIO()):
+        out = localize_batch(jm, mixes)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cands = sum(r["spot_times"] for r in out)
+    stages = np.array([r["times"] for r in out]).sum(0)
+    print(json.dumps({"workload": "64 five-speaker mixtures, 7 mics, T=%d, full search each, 1 GPU" % T,
+                      "mixtures_per_s": round(n_mix / dt, 2), "s_total": round(dt, 2),
+                      "spot_candidates": int(cands), "candidates_per_s_in_search": round(cands / dt, 1),
+                      "talkers_found_mean": round(float(np.mean([len(r["names"]) for r in out])), 2),
+                      "stage_seconds": {k: round(float(v), 2) for k, v in
+                                        zip(["srp_phat", "coarse", "fine", "clustering", "joint_sep"], stages)}}))
+
+
+if __name__ == "__main__":
+    main()
