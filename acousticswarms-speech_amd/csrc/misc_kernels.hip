@@ -300,6 +300,50 @@ __global__ __launch_bounds__(256) void pair_sisdr_kernel(const float* __restrict
   }
 }
 
+// Segment-wise SI-SDR (split_wise_sisdr, sep/helpers/eval_utils.py:73-82; call site
+// Mic_Array.py:432-458): for every ordered pair (i = estimate, j = reference) the SI-SDR over
+// each voiced segment [a,b) of waveform i.  Block (i, j) walks i's segments; per segment the
+// same two passes and float32 element arithmetic as pair_sisdr_kernel.
+__global__ __launch_bounds__(256) void seg_sisdr_kernel(const float* __restrict__ y, int T, const int* __restrict__ seg,
+                                                        const int* __restrict__ cnt, int kmax,
+                                                        double* __restrict__ out) {
+  __shared__ double red[4][2];
+  const int i = blockIdx.x, j = blockIdx.y, n = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nseg = cnt[i];
+  for (int k = 0; k < nseg; ++k) {
+    const int a0i = seg[((long)i * kmax + k) * 2], b0i = seg[((long)i * kmax + k) * 2 + 1];
+    const float* e = y + (long)i * T + a0i;
+    const float* s = y + (long)j * T + a0i;
+    const int len = b0i - a0i;
+    double a0 = 0, a1 = 0;
+    for (int t = tid; t < len; t += 256) { a0 += (double)(s[t] * s[t]); a1 += (double)(s[t] * e[t]); }
+    a0 = wave_sum_d(a0); a1 = wave_sum_d(a1);
+    __syncthreads();                                   // red[] of the previous segment consumed
+    if (lane == 0) { red[wid][0] = a0; red[wid][1] = a1; }
+    __syncthreads();
+    const float rss = (float)(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    const float rse = (float)(red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    const float a = rse / rss;
+    __syncthreads();
+    double b0 = 0, b1 = 0;
+    for (int t = tid; t < len; t += 256) {
+      const float tr = a * s[t];
+      const float rs = e[t] - tr;
+      b0 += (double)(tr * tr);
+      b1 += (double)(rs * rs);
+    }
+    b0 = wave_sum_d(b0); b1 = wave_sum_d(b1);
+    if (lane == 0) { red[wid][0] = b0; red[wid][1] = b1; }
+    __syncthreads();
+    if (tid == 0) {
+      const double sss = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+      const double snn = red[0][1] + red[1][1] + red[2][1] + red[3][1] + 1e-8;
+      out[((long)i * n + j) * kmax + k] = 10.0 * log10(sss / snn);
+    }
+  }
+}
+
 // x[b][:] -= mean(x[b][:])   (sep/Mic_Array.py:291: the stage loops centre every candidate
 // output before measuring / comparing it); mean accumulated in double, applied as float32
 __global__ __launch_bounds__(1024) void center_rows_kernel(float* __restrict__ y, int T) {
@@ -449,6 +493,16 @@ extern "C" int asw_energies(const float* y, int B, int T, int window, double* sc
   ASW_CHECK_ARG(T > 0 && window > 0, "energies: bad shape");
   if (B == 0) return ASW_OK;
   hipLaunchKernelGGL(energy_kernel, dim3(B), dim3(1024), 0, asw::as_stream(stream), y, T, window, scratch, out);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+extern "C" int asw_segment_sisdr(const float* y, int n, int T, const int32_t* segments, const int32_t* seg_count,
+                                 int kmax, double* out, void* stream) {
+  ASW_CHECK_ARG(y && segments && seg_count && out, "segment_sisdr: null pointer");
+  ASW_CHECK_ARG(n > 0 && n <= 65535 && T > 0 && kmax > 0, "segment_sisdr: bad shape");
+  hipLaunchKernelGGL(seg_sisdr_kernel, dim3(n, n), dim3(256), 0, asw::as_stream(stream), y, T, segments, seg_count,
+                     kmax, out);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }

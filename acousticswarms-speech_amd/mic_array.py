@@ -85,6 +85,7 @@ class MicArray(object):
         self.original_times = 0
         self.spotforming_times = 0
         self.big_spotforming_times = 0
+        self._device_scorer = None      # set by the fine stage when the spot model offers the GPU SI-SDR kernels
 
     # ---- stage 1: SRP-PHAT pruning (sep/Mic_Array.py:152-194) ---------------------------
     def Apply_SRP_PHAT(self, mix_data):
@@ -148,6 +149,8 @@ class MicArray(object):
         # the cluster heads' waveforms are copied to the host.  Any other
         # duck-typed model goes through the reference's host loops.
         resident = hasattr(spot_model, "shift_and_sep_resident")
+        inner = getattr(spot_model, "inner", spot_model)                 # ShardedSpotModel wraps the scorer
+        self._device_scorer = inner if (resident and hasattr(inner, "segment_sisdr")) else None
         if len(total_patch) == 0:                          # a rank that was dealt no coarse patch
             waves_dev, energies, sep_all = None, np.zeros((0, 2)), None
             T_len = int(mix_data.shape[1])
@@ -234,11 +237,23 @@ class MicArray(object):
     # ---- stage 4: global non-max suppression (sep/Mic_Array.py:399-500) -----------------
     def Clustering_new(self, output_pair, simple_pos=None, sample_gt=None):
         cands = sorted(output_pair, key=lambda x: -x[2])
+        # With the HIP spot model the O(n^2) waveform comparisons of this stage run on the GPU:
+        # one launch for the full-length SI-SDR matrix, one for the segment-wise tensor
+        # (SURVEY.md §8f-2).  Any other model keeps the reference's host loops.
+        scorer = getattr(self, "_device_scorer", None)
+        seg_all = [split_wav(c[1]) for c in cands]
+        full_dev = seg_dev = None
+        if scorer is not None and len(cands) > 1:
+            import torch
+            waves = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(c[1], dtype=np.float32) for c in cands])))
+            waves = waves.to(scorer.device if getattr(scorer, "device", None) is not None else "cuda")
+            full_dev = scorer.pair_sisdr(waves)
+            seg_dev, _ = scorer.segment_sisdr(waves, seg_all)
         clusters = {}
         wrong = []
         for i, cand in enumerate(cands):
             centre1, audio1, power1, big_label = cand[0].center_pos(), cand[1], cand[2], cand[-1]
-            segs = split_wav(audio1)
+            segs = seg_all[i]
             if len(segs) == 0:
                 print("discard because no invalid split!!!")
                 continue
@@ -247,8 +262,12 @@ class MicArray(object):
             for head in clusters:
                 h = clusters[head][0]
                 audio2, centre2 = cands[h][1], cands[h][0].center_pos()
-                sim = si_sdr(audio1, audio2)
-                per_seg = split_wise_sisdr(audio1, audio2, segs)
+                if full_dev is not None:
+                    sim = full_dev[i, h]
+                    per_seg = list(seg_dev[i, h, :len(segs)])
+                else:
+                    sim = si_sdr(audio1, audio2)
+                    per_seg = split_wise_sisdr(audio1, audio2, segs)
                 seg_tab.append(per_seg)
                 dis = np.linalg.norm(centre1[:2] - centre2[:2])
                 if sim > -1 or check_sisnr_win(per_seg) or dis < 0.45:      # (:401,458)

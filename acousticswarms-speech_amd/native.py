@@ -99,6 +99,7 @@ SIGNATURES = {
     "asw_energies": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asw_pair_sisdr": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "asw_center_rows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "asw_segment_sisdr": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "asw_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "asw_search_area": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_double, c_double,
                                 POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),

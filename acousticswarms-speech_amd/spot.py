@@ -213,6 +213,31 @@ class SpotModel:
                                                          native.current_stream()))
         return out.cpu().numpy()
 
+    def segment_sisdr(self, waves, segments):
+        """Segment-wise SI-SDR tensor S[i][j][k] = si_sdr(waves[i][seg_k(i)], waves[j][seg_k(i)])
+        on the GPU (split_wise_sisdr, sep/helpers/eval_utils.py:73-82): ``segments[i]`` is the
+        list of [start, end) of waveform i (split_wav).  Returns (host ndarray [n,n,kmax]
+        float64, counts [n]); entries beyond a waveform's segment count are NaN."""
+        import torch
+        n, T = waves.shape
+        cnt = np.array([len(s) for s in segments], dtype=np.int32)
+        kmax = max(1, int(cnt.max()) if n else 1)
+        seg = np.zeros((n, kmax, 2), dtype=np.int32)
+        for i, sl in enumerate(segments):
+            for k, (a, b) in enumerate(sl):
+                if not (0 <= a <= b <= T):
+                    raise RuntimeError(f"segment [{a},{b}) of waveform {i} lies outside [0,{T}]")
+                seg[i, k] = (a, b)
+        out = torch.full((n, n, kmax), float("nan"), dtype=torch.float64, device=waves.device)
+        if n > 0:
+            with torch.cuda.device(waves.device):
+                seg_d = torch.from_numpy(seg).to(waves.device)
+                cnt_d = torch.from_numpy(cnt).to(waves.device)
+                native.check(native.lib().asw_segment_sisdr(native.ptr(waves.contiguous()), n, T, native.ptr(seg_d),
+                                                            native.ptr(cnt_d), kmax, native.ptr(out),
+                                                            native.current_stream()))
+        return out.cpu().numpy(), cnt
+
     def forward(self, mix, window_embedding):
         """Network.forward: mix [B,M,t] (already normalised), window_embedding [B,2] -> [B,1,t]
         (device tensor).  Rows are grouped by identical embedding because the window gate

@@ -234,6 +234,14 @@ int asw_center_rows(float* y, int B, int T, void* stream);
  * call sites Mic_Array.py:353,432).  out [n][n] float64. */
 int asw_pair_sisdr(const float* y, int n, int T, double* out, void* stream);
 
+/* Segment-wise SI-SDR of every ordered pair (split_wise_sisdr, eval_utils.py:73-82; call site
+ * Mic_Array.py:432-458): segments [n][kmax][2] int32 = the [start,end) voiced segments of
+ * waveform i (split_wav), seg_count [n]; out [n][n][kmax] float64, entry (i,j,k) = SI-SDR of
+ * est = y[i][seg k of i] against ref = y[j][same samples]; entries k >= seg_count[i] are left
+ * untouched.  Segment bounds must lie in [0,T] (device arrays). */
+int asw_segment_sisdr(const float* y, int n, int T, const int32_t* segments, const int32_t* seg_count,
+                      int kmax, double* out, void* stream);
+
 /* HOST function (no GPU): breadth-first subdivision of one coarse hypercube into the fine
  * candidate hypercubes -- search_area / binary_area_divide_width
  * (sep/helpers/local_utils_3d.py:212-335) with Patch.check_out / hyperbola_sample
