@@ -24,17 +24,29 @@ constexpr double MIN_WIDTH_REQUIRED = 2;
 struct Cell {
   std::vector<double> off, width;
   std::vector<int> idx;                    // indices into the coarse patch's point list
+  bool filtered = false;                   // every point of idx passed the box test of THIS box
 };
 
-void check_out(Cell& c, const double* ub, int P) {   // Patch_3D.py:69-87
+bool check_out(Cell& c, const double* ub, int P) {   // Patch_3D.py:69-87; true if the box moved
+  bool moved = false;
   for (int i = 0; i < P; ++i) {
     while (std::fabs(c.off[i]) > ub[i] && c.width[i] > 4) {
       const double res = c.width[i];
       if (c.off[i] > ub[i]) c.off[i] = c.off[i] - res / 4;
       else if (c.off[i] < -ub[i]) c.off[i] = c.off[i] + res / 4;
       c.width[i] = res / 2;
+      moved = true;
     }
   }
+  return moved;
+}
+
+// the same test on one pair only: enough for a child whose parent's points already passed the
+// parent's box (the halves differ from it in that pair alone)
+inline bool inside_dim(const double* s, long n_pts, int p_idx, int i, const double* off, const double* width) {
+  const double half = width[i] / 2 + 1e-3;
+  const double v = s[(long)i * n_pts + p_idx];
+  return v >= off[i] - half && v <= off[i] + half;
 }
 
 // box test +-width/2 (+-1e-3) on every pair (Patch_3D.py:40-47)
@@ -79,7 +91,7 @@ extern "C" int asw_search_area(const double* points, int n_pts, const double* mi
   while (!frontier.empty()) {
     std::vector<Cell> next;
     for (Cell& c : frontier) {
-      if (ub) check_out(c, ub, P);
+      if (ub && check_out(c, ub, P)) c.filtered = false;
       if (first) {                                     // the caller's patch is mutated (a-L)
         std::memcpy(offset, c.off.data(), sizeof(double) * P);
         std::memcpy(width, c.width.data(), sizeof(double) * P);
@@ -104,8 +116,14 @@ extern "C" int asw_search_area(const double* points, int n_pts, const double* mi
           k.width = c.width;
           k.width[i] /= 2;
           half_w = k.width[i];
-          for (int pj : c.idx)
-            if (inside(samples.data(), n_pts, pj, k.off.data(), k.width.data(), P)) k.idx.push_back(pj);
+          if (c.filtered) {
+            for (int pj : c.idx)
+              if (inside_dim(samples.data(), n_pts, pj, i, k.off.data(), k.width.data())) k.idx.push_back(pj);
+          } else {
+            for (int pj : c.idx)
+              if (inside(samples.data(), n_pts, pj, k.off.data(), k.width.data(), P)) k.idx.push_back(pj);
+          }
+          k.filtered = true;
           sizes[sgn] = (long)k.idx.size();
           if (!k.idx.empty()) kids.push_back(std::move(k));
         }

@@ -34,6 +34,7 @@ class Patch(object):
         self.area_points = area_points                     # float64 [3,n] or None
         self.num_pair = sample_offset.shape[0]
         self.peak_pos = peak_pos
+        self._centroid = None                              # (points array it was computed from, value)
 
     # ---- geometry ---------------------------------------------------------------
     def area_size(self):
@@ -45,9 +46,13 @@ class Patch(object):
         """peak position if known, else the centroid of the contained points (:19-26)."""
         if self.peak_pos is not None:
             return self.peak_pos
-        if self.area_points is None or self.area_points.shape[1] == 0:
+        ap = self.area_points
+        if ap is None or ap.shape[1] == 0:
             return None
-        return np.mean(self.area_points, axis=1)
+        c = self._centroid
+        if c is None or c[0] is not ap:                    # the stage loops ask for the same centroid many times
+            c = self._centroid = (ap, np.mean(ap, axis=1))
+        return c[1].copy()
 
     def _inside(self, offsets: np.ndarray) -> np.ndarray:
         """Box test +-width/2 (+-1e-3) on offsets [P, n] (:36-37,44-45)."""
