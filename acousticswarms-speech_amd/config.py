@@ -5,7 +5,7 @@ Mirrors the constructor arguments of the reference spot ``Network``
 experiments/localization/description.json:5-13.  Only shapes live here; no
 arithmetic of the path.
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Tuple
 
 

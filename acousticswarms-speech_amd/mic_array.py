@@ -7,7 +7,6 @@ reference including its order-dependent quirks (documented inline).
 """
 import numpy as np
 
-from . import search
 from .hostdsp import max_avg_power, si_sdr, split_wav, split_wise_sisdr
 from .patch import FS, SPEED_OF_SOUND, Patch, pair_offsets
 from .search import (INIT_WIDTH, SPOT_POWER_THRESHOLD2, USE_RELATIVE_SPOT_POWER, binary_search_baseline,

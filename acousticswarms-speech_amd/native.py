@@ -8,7 +8,7 @@ import ctypes
 import os
 import subprocess
 import sys
-from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
                     c_long, c_size_t, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

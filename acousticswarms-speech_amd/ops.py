@@ -8,7 +8,6 @@ from ctypes import byref
 
 import torch
 
-from . import native
 from .native import ConvGemmArgs, check, current_stream, lib, ptr
 
 

@@ -21,7 +21,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 # MI355X_MICROARCH.md: dense f32 matrix peak (exact fp32 MFMA) and dense f16 MFMA peak.  In the
