@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--samples", type=int, default=48000)
     ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--host-energies", action="store_true",
+                    help="include the reference's host-side energy loop in the timed region")
     args = ap.parse_args()
     from acousticswarms_speech_amd.config import FULL
     from acousticswarms_speech_amd.scenes import make_scene, random_offsets
@@ -50,6 +52,10 @@ def main():
             y = spot_ref.spot_forward(sd, FULL, dn, w.expand(len(chunk), 2))
             outs.append(spot_ref.unnormalize_input(y, mu, sg)[:, 0])
         r = torch.cat(outs).cpu().numpy()
+        if args.host_energies:
+            # the reference then scores every candidate on the host (mean removal, sum of squares,
+            # windowed RMS through scipy's uniform_filter1d: local_utils_3d.py:13-17,349-354)
+            spot_ref.candidate_energies(r)
         return r
 
     run()
@@ -63,7 +69,8 @@ def main():
     dt = min(ts)
     print(json.dumps({"what": "reference-style GPU path (stock PyTorch-ROCm ops, oracle statement)",
                       "candidates_per_s": args.candidates / dt, "candidates": args.candidates,
-                      "batch": args.batch, "T": args.samples, "seconds": dt, "dtype": "f32"}))
+                      "batch": args.batch, "T": args.samples, "seconds": dt, "dtype": "f32",
+                      "host_energies_included": bool(args.host_energies)}))
 
 
 if __name__ == "__main__":
