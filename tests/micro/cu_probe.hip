@@ -38,6 +38,27 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, int iters) {
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// ---- the 16x16x32 shape of the same pipe (4 accumulator registers instead of 16)
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma16(float* out, int iters) {
+  floatx4 acc[NACC];
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+  half8 a, b;
+  unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  for (int r = 0; r < 8; ++r) {
+    h = h * 1664525u + 1013904223u; a[r] = (_Float16)(((int)(h >> 16) & 4095) * (1.0f / 2048.0f) - 1.0f);
+    h = h * 1664525u + 1013904223u; b[r] = (_Float16)(((int)(h >> 16) & 4095) * (1.0f / 2048.0f) - 1.0f);
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 // ---- LDS fragment reads only (ds_read_b128, rows of 272 B like the halo image)
 template <int NR>
 __global__ __launch_bounds__(256) void k_lds(float* out, int iters) {
@@ -164,6 +185,13 @@ template <int NACC, int CH> void run_mfma(const char* tag) {
   const double cyc = ms * 1e-3 * g_ghz * 1e9;
   printf("%-44s wgs/cu %d: %.1f cycles per MFMA per SIMD (%.0f TFLOP/s)\n", tag, g_wgs, cyc / (mf / (g_cus * 4)), mf * 32768 / ms * 1e-9);
 }
+template <int NACC> void run_mfma16(const char* tag) {
+  auto L = []() { hipLaunchKernelGGL((k_mfma16<NACC>), dim3(g_cus * g_wgs), dim3(256), 0, 0, g_out, g_iters); };
+  const double ms = time_ms(L);
+  const double mf = (double)g_cus * g_wgs * 4 * g_iters * NACC;
+  const double cyc = ms * 1e-3 * g_ghz * 1e9;
+  printf("%-44s wgs/cu %d: %.1f cycles per MFMA per SIMD (%.0f TFLOP/s)\n", tag, g_wgs, cyc / (mf / (g_cus * 4)), mf * 16384 / ms * 1e-9);
+}
 template <int NR> void run_lds() {
   auto L = []() { hipLaunchKernelGGL((k_lds<NR>), dim3(g_cus * g_wgs), dim3(256), 48 * 1024, 0, g_out, g_iters); };
   const double ms = time_ms(L);
@@ -212,6 +240,7 @@ int main() {
   for (int w : {1, 2}) {
     g_wgs = w;
     run_mfma<4, 3>("MFMA 4 accumulators, 3 in a row, random operands");
+    run_mfma16<8>("MFMA 16x16x32, 8 accumulators, random operands");
     g_iters = -2000;
     run_mfma<4, 3>("MFMA 4 accumulators, 3 in a row, ZERO operands");
     g_iters = 2000;
