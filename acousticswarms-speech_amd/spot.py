@@ -18,13 +18,14 @@ from .config import FULL, SpotConfig, spot_param_shapes
 
 def offsets_from_patches(patch_list, n_pairs: int) -> np.ndarray:
     """round(sample_offset) per candidate as int32 [N, M-1]
-    (JointModel/network.py:81-82: torch.round is round-half-even == np.rint)."""
+    (JointModel/network.py:81-82: the offsets pass through a float32 torch.Tensor before
+    torch.round, which is round-half-even == np.rint on the float32 value)."""
     if len(patch_list) == 0:
         return np.zeros((0, n_pairs), dtype=np.int32)
     offs = np.stack([np.asarray(getattr(p, "sample_offset", p), dtype=np.float64) for p in patch_list])
     if offs.shape[1] != n_pairs:
         raise RuntimeError(f"candidate has {offs.shape[1]} offsets, mixture has {n_pairs + 1} channels")
-    return np.rint(offs).astype(np.int32)
+    return np.rint(offs.astype(np.float32)).astype(np.int32)
 
 
 class SpotModel:
