@@ -235,3 +235,37 @@ def test_full_size_properties(T):
     # the two window embeddings are different networks (gates folded into the weights)
     en_relaxed = m.shift_and_score(mix, patches[:3], Strict=0)
     assert not np.array_equal(en_relaxed, en13[:3])
+
+
+@pytest.mark.parametrize("M,T", [(2, 257), (7, 1000), (3, 4097)])
+def test_edge_shapes_vs_oracle(M, T):
+    """Ragged and extreme inputs of the hot call: the smallest array (2 mics), lengths that are
+    not multiples of the 256-sample frame, offsets beyond +-T (the circular shift wraps more than
+    once), a single candidate and a ragged last internal batch."""
+    import dataclasses
+    from acousticswarms_speech_amd.config import SMALL
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    from oracle import spot_ref
+    cfg = dataclasses.replace(SMALL, n_mics=M)
+    sd = make_spot_state_dict(cfg, 40 + M)
+    m = _model(cfg, 40 + M, batch=4)
+    rng = np.random.default_rng(M * 1000 + T)
+    mix = torch.from_numpy((rng.standard_normal((M, T)) * 0.1).astype(np.float32))
+    offs = rng.integers(-40, 41, size=(9, M - 1))
+    offs[1] = 0
+    offs[2] = T + 3                                             # wraps once more than the length
+    offs[3] = -(2 * T + 5)
+    offs[4] = T // 2
+
+    class P:
+        def __init__(self, o):
+            self.sample_offset = o
+    for n in (1, 9):
+        patches = [P(o) for o in offs[:n]]
+        for strict in (0, 1):
+            y = m.shift_and_sep(mix, patches, Strict=strict)
+            ref = spot_ref.shift_and_sep(sd, cfg, mix, [p.sample_offset for p in patches], strict=strict)
+            assert y.shape == ref.shape == (n, T)
+            per = [snr_db(y[i], ref[i]) for i in range(n)]
+            assert min(per) > 80.0, (M, T, n, strict, per)
+    _log(f"edge shapes M={M} T={T}: ok")
