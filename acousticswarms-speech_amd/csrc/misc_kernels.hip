@@ -451,7 +451,7 @@ extern "C" int asw_attention(const float* qkv, int B, int L, int d, int nhead, f
   ASW_CHECK_ARG(B > 0 && L > 0 && nhead > 0 && d % nhead == 0, "attention: bad shape");
   ASW_CHECK_ARG(B <= 65535 && nhead <= 65535, "attention: grid too large");
   {
-    const int rc = asw::attention_mfma(qkv, B, L, d, nhead, ctx, asw::as_stream(stream));   // L <= 192, hd 128
+    const int rc = asw::attention_mfma(qkv, B, L, d, nhead, ctx, asw::as_stream(stream));   // head_dim 128: MFMA kernels
     if (rc != 1) return rc;
   }
   const int hd = d / nhead;
