@@ -296,3 +296,26 @@ def test_two_rank_sharded_search_with_hip_model(mic_array):
     _log(f"two-rank sharded search: pairs {len(want[1])}, final {len(want[4])}, candidates evaluated per rank "
          f"{[r[7] for r in res]} of {want[5]}")
     assert total_eval == want[5]                                        # each candidate evaluated exactly once
+
+
+def test_evaluation_record_with_hip_model(tmp_path):
+    """The evaluation harness end to end on the GPU path: a sample directory in the reference's
+    format -> JointModel with the HIP spot model -> result record + result_<sample>.json."""
+    import json
+    from acousticswarms_speech_amd import evalkit
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.joint import JointModel
+    from acousticswarms_speech_amd.scenes import make_scene
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    sc = make_scene(1001, 3, 7, 24000)
+    evalkit.write_scene_dir(sc, str(tmp_path / "ds" / "00000"))
+    jm = JointModel(SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=64, precision="f16x3").to("cuda"),
+                    None, device="cuda")
+    with redirect_stdout(io.StringIO()):
+        summary = evalkit.evaluate_dataset(jm, str(tmp_path / "ds"), str(tmp_path / "res"))
+    rec = json.load(open(tmp_path / "res" / "result_00000.json"))
+    assert summary["tp"] + summary["fn"] == 3 and summary["tp"] == len(rec["pred"])
+    assert len(rec["gt"]) == 3 and len(rec["mic_pos"]) == 7
+    assert summary["fp"] == len(rec["false_positive"])
+    _log(f"evaluation record: tp={summary['tp']} fp={summary['fp']} fn={summary['fn']} (random weights)")
