@@ -106,23 +106,102 @@ class MicArray(object):
         return kept
 
     # ---- stage 3: fine Spotforming, strict window (sep/Mic_Array.py:225-395) ------------
+    def _subdivide(self, big):
+        """Fine candidates of one coarse patch: its hypercube subdivision plus the centre
+        candidate, which goes last (sep/Mic_Array.py:245-262)."""
+        P = self.num_mic - 1
+        fine = search_area([big], self.mic_positions, self.upper_bound_pairwise)
+        centre_patch = Patch(big.sample_offset, [2 for _ in range(P)], None, big.peak_pos)
+        c = centre_patch.center_pos()
+        if c is not None:
+            fine.append(centre_patch)
+        else:
+            print("it is impossible to be here")
+        return fine, c
+
+    def _cluster_group(self, g, big, patches, powers, powers2, area, centre, T_len, thr_new, sample_gt,
+                       sim_of, audio_of):
+        """Thresholding + SI-SDR clustering of the candidates of ONE coarse patch and the output
+        tuples of its cluster heads (sep/Mic_Array.py:283-383).  ``sim_of(k, h)`` gives
+        si_sdr(candidate k, candidate h); ``audio_of(heads)`` the heads' waveforms."""
+        out = []
+        big_label = -1
+        if sample_gt is not None:
+            for k in range(sample_gt.shape[1]):
+                if np.amax(np.abs(big.sample_offset - sample_gt[:, k])) < 3.5:
+                    big_label = k
+                    break
+        c = big.center_pos()
+        d = np.linalg.norm(c - self.mic_positions[0]) if c.shape[0] == 3 else 4
+        if np.amax(powers2) < thr_new / (1 + d):
+            return out
+        order = np.argsort(-1 * np.array(powers))                           # sorted by total power (:339)
+        clusters = {}
+        # the reference scales the trigger by the length of the LAST candidate row (:343)
+        min_trigger = self.MIN_TRIGGER_POWER / (3 * 48000) * T_len
+        for k in order:
+            d = np.linalg.norm(patches[k].center_pos() - self.mic_positions[0])
+            if powers2[k] < thr_new / (1 + d) or powers[k] < min_trigger:
+                continue
+            home = None
+            for head in clusters:
+                if sim_of(k, clusters[head][0]) > -4:                       # SI_SDR_THRESHOLD (:340)
+                    home = head
+                    break
+            if home is None:
+                clusters[k] = [k]
+            else:
+                clusters[home].append(k)
+        if len(clusters) == 0:
+            return out
+        heads = list(clusters.keys())
+        audio = audio_of(heads)
+        area_samples = None
+        for n, head in enumerate(heads):
+            _position, offs = weight_mean_pos(patches, powers, clusters[head])
+            if area_samples is None:                                        # once per coarse patch
+                area_samples = pair_offsets(area, self.mic_positions, SPEED_OF_SOUND, FS)
+            merged = find_merge_center(offs, area, self.mic_positions, centre, area_samples)
+            if merged.center_pos() is None:
+                print("Warning some bug happen one source may be drop")
+            out.append((merged, audio[n], powers[head], str(g) + '_' + str(head),
+                        {"audio_offset": patches[head].sample_offset, "localization_offset": offs}, big_label))
+        return out
+
+    def _resident_group(self, g, big, patches, waves_g, energies_g, area, centre, T_len, thr_new, sample_gt,
+                        spot_model):
+        """One coarse patch with the waveforms on the GPU: similarities from one Gram launch (made
+        only if a second candidate survives the thresholds), heads copied to the host."""
+        sim = {}
+
+        def sim_of(k, h):
+            if "m" not in sim:
+                sim["m"] = spot_model.pair_sisdr(waves_g)
+            return sim["m"][k, h]
+
+        def audio_of(heads):
+            return waves_g[heads].cpu().numpy()
+        return self._cluster_group(g, big, patches, list(energies_g[:, 0]), list(energies_g[:, 1]), area, centre,
+                                   T_len, thr_new, sample_gt, sim_of, audio_of)
+
     def Spotform_Small_Patch_Parallel(self, mix_data, candidate_finished, spot_model, sample_gt=None,
                                       run_demo_folder=None):
-        P = self.num_mic - 1
         thr_new = min([SPOT_POWER_THRESHOLD2, self.Relative_Threshold]) if USE_RELATIVE_SPOT_POWER \
             else SPOT_POWER_THRESHOLD2
-        total_patch, bounds, areas, centers = [], [0], [], []
+        resident = hasattr(spot_model, "shift_and_sep_resident")
+        inner = getattr(spot_model, "inner", spot_model)                 # ShardedSpotModel wraps the scorer
+        self._device_scorer = inner if (resident and hasattr(inner, "segment_sisdr")) else None
+        sharded = getattr(spot_model, "world", 1) > 1
+        n_groups = len(candidate_finished)
         self.spotforming_times = 0
+        if resident and not sharded and n_groups >= 3 and getattr(spot_model, "device", None) is not None:
+            return self._fine_stage_pipelined(mix_data, candidate_finished, spot_model, sample_gt, thr_new)
+
+        total_patch, bounds, areas, centers = [], [0], [], []
         for big in candidate_finished:
-            fine = search_area([big], self.mic_positions, self.upper_bound_pairwise)
+            fine, c = self._subdivide(big)
             areas.append(big.area_points)
-            centre_patch = Patch(big.sample_offset, [2 for _ in range(P)], None, big.peak_pos)
-            c = centre_patch.center_pos()
             centers.append(c)
-            if c is not None:
-                fine.append(centre_patch)                 # the centre candidate goes last (:256-257)
-            else:
-                print("it is impossible to be here")
             self.spotforming_times += len(fine)
             total_patch.extend(fine)
             bounds.append(self.spotforming_times)
@@ -130,8 +209,6 @@ class MicArray(object):
         # one rank per GPU (shard.ShardedSpotModel): whole coarse patches are dealt to ranks so
         # the per-patch clustering below stays local; energies are all-gathered (the stage's one
         # collective) and only the finished output tuples travel.
-        sharded = getattr(spot_model, "world", 1) > 1
-        n_groups = len(bounds) - 1
         mine = spot_model.my_groups([bounds[i + 1] - bounds[i] for i in range(n_groups)]) if sharded \
             else list(range(n_groups))
         if sharded:
@@ -147,9 +224,6 @@ class MicArray(object):
         # from the device reduction, SI-SDR similarities from the device Gram kernel, and only
         # the cluster heads' waveforms are copied to the host.  Any other
         # duck-typed model goes through the reference's host loops.
-        resident = hasattr(spot_model, "shift_and_sep_resident")
-        inner = getattr(spot_model, "inner", spot_model)                 # ShardedSpotModel wraps the scorer
-        self._device_scorer = inner if (resident and hasattr(inner, "segment_sisdr")) else None
         if len(total_patch) == 0:                          # a rank that was dealt no coarse patch
             waves_dev, energies, sep_all = None, np.zeros((0, 2)), None
             T_len = int(mix_data.shape[1])
@@ -166,71 +240,77 @@ class MicArray(object):
         for g in mine:
             i = slot[g]                                                     # local slot of coarse patch g
             big = candidate_finished[g]
-            big_label = -1
-            if sample_gt is not None:
-                for k in range(sample_gt.shape[1]):
-                    if np.amax(np.abs(big.sample_offset - sample_gt[:, k])) < 3.5:
-                        big_label = k
-                        break
             patches = total_patch[bounds[i]:bounds[i + 1]]
             if resident:
-                powers = list(energies[bounds[i]:bounds[i + 1], 0])
-                powers2 = list(energies[bounds[i]:bounds[i + 1], 1])
-            else:
-                sep = sep_all[bounds[i]:bounds[i + 1]]
-                powers, powers2 = [], []
-                for j in range(len(patches)):
-                    sep[j, :] = sep[j, :] - np.mean(sep[j, :])                 # in place, as :291
-                    powers.append(np.sum(sep[j, :] ** 2))
-                    powers2.append(max_avg_power(sep[j, :]))
-            c = big.center_pos()
-            d = np.linalg.norm(c - self.mic_positions[0]) if c.shape[0] == 3 else 4
-            if np.amax(powers2) < thr_new / (1 + d):
+                output_pair.extend(self._resident_group(g, big, patches, waves_dev[bounds[i]:bounds[i + 1]],
+                                                        energies[bounds[i]:bounds[i + 1]], areas[g], centers[g],
+                                                        T_len, thr_new, sample_gt, spot_model))
                 continue
-            order = np.argsort(-1 * np.array(powers))                       # sorted by total power (:339)
-            clusters = {}
-            # the reference scales the trigger by the length of the LAST candidate row (:343)
-            min_trigger = self.MIN_TRIGGER_POWER / (3 * 48000) * T_len
-            sim = None
-            for k in order:
-                d = np.linalg.norm(patches[k].center_pos() - self.mic_positions[0])
-                if powers2[k] < thr_new / (1 + d) or powers[k] < min_trigger:
-                    continue
-                home = None
-                for head in clusters:
-                    if resident:
-                        if sim is None:                                     # one Gram launch per coarse patch
-                            sim = spot_model.pair_sisdr(waves_dev[bounds[i]:bounds[i + 1]])
-                        s_kh = sim[k, clusters[head][0]]
-                    else:
-                        s_kh = si_sdr(sep[k, :], sep[clusters[head][0]])
-                    if s_kh > -4:                                           # SI_SDR_THRESHOLD (:340)
-                        home = head
-                        break
-                if home is None:
-                    clusters[k] = [k]
-                else:
-                    clusters[home].append(k)
-            if len(clusters) == 0:
-                continue
-            if resident:
-                heads = list(clusters.keys())
-                head_audio = waves_dev[[bounds[i] + h for h in heads]].cpu().numpy()
-                audio_of = {h: head_audio[n] for n, h in enumerate(heads)}
-            area_samples = None
-            for head in clusters:
-                _position, offs = weight_mean_pos(patches, powers, clusters[head])
-                if area_samples is None:                                    # once per coarse patch
-                    area_samples = pair_offsets(areas[g], self.mic_positions, SPEED_OF_SOUND, FS)
-                centre = find_merge_center(offs, areas[g], self.mic_positions, centers[g], area_samples)
-                if centre.center_pos() is None:
-                    print("Warning some bug happen one source may be drop")
-                audio = audio_of[head] if resident else sep[head, :]
-                output_pair.append((centre, audio, powers[head], str(g) + '_' + str(head),
-                                    {"audio_offset": patches[head].sample_offset, "localization_offset": offs},
-                                    big_label))
+            sep = sep_all[bounds[i]:bounds[i + 1]]
+            powers, powers2 = [], []
+            for j in range(len(patches)):
+                sep[j, :] = sep[j, :] - np.mean(sep[j, :])                 # in place, as :291
+                powers.append(np.sum(sep[j, :] ** 2))
+                powers2.append(max_avg_power(sep[j, :]))
+            output_pair.extend(self._cluster_group(
+                g, big, patches, powers, powers2, areas[g], centers[g], T_len, thr_new, sample_gt,
+                lambda k, h, sep=sep: si_sdr(sep[k, :], sep[h]), lambda heads, sep=sep: [sep[h, :] for h in heads]))
         if sharded:
             output_pair = spot_model.gather_pairs(output_pair)
+        return output_pair
+
+    def _fine_stage_pipelined(self, mix_data, candidate_finished, spot_model, sample_gt, thr_new):
+        """Single-GPU fine stage with the host work hidden behind the GPU: the coarse patches are
+        processed in three contiguous chunks; while the GPU evaluates the candidates of chunk c
+        the host subdivides the patches of chunk c+1, and the clustering of chunk c (energies,
+        Gram launches, head copies -- issued on a side stream that only waits for chunk c) runs
+        while the GPU is already on chunk c+1.  Same candidates, same order, same output."""
+        import torch
+        dev = spot_model.device
+        mix_dev = torch.as_tensor(mix_data).to(dev, dtype=torch.float32).contiguous()
+        T_len = int(mix_dev.shape[1])
+        n_groups = len(candidate_finished)
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        side, main = self._side_stream, torch.cuda.current_stream(dev)
+        n_chunks = 3
+        edges = [round(n_groups * k / n_chunks) for k in range(n_chunks + 1)]
+        output_pair, inflight = [], None
+
+        def finish(job):
+            groups, fines, centres, waves, en_dev, ev = job
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                waves.record_stream(side)
+                en_dev.record_stream(side)
+                energies = en_dev.cpu().numpy()
+                pos = 0
+                for g, fine, centre in zip(groups, fines, centres):
+                    n = len(fine)
+                    output_pair.extend(self._resident_group(
+                        g, candidate_finished[g], fine, waves[pos:pos + n], energies[pos:pos + n],
+                        candidate_finished[g].area_points, centre, T_len, thr_new, sample_gt, spot_model))
+                    pos += n
+
+        for k in range(n_chunks):
+            groups = list(range(edges[k], edges[k + 1]))
+            if not groups:
+                continue
+            fines, centres, flat = [], [], []
+            for g in groups:                                   # host: subdivision of this chunk
+                fine, c = self._subdivide(candidate_finished[g])
+                fines.append(fine)
+                centres.append(c)
+                flat.extend(fine)
+                self.spotforming_times += len(fine)
+            waves, en_dev = spot_model.shift_and_sep_resident(mix_dev, flat, Strict=1, device_energies=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            if inflight is not None:
+                finish(inflight)                               # host clustering of the previous chunk
+            inflight = (groups, fines, centres, waves, en_dev, ev)
+        if inflight is not None:
+            finish(inflight)
         return output_pair
 
     # ---- stage 4: global non-max suppression (sep/Mic_Array.py:399-500) -----------------

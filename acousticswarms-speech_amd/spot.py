@@ -184,23 +184,29 @@ class SpotModel:
         self.last_waveforms = wave
         return en.cpu().numpy()
 
-    def shift_and_sep_resident(self, input_channels, patch_list, Strict: int = 0, window: int = 12000):
+    def shift_and_sep_resident(self, input_channels, patch_list, Strict: int = 0, window: int = 12000,
+                               device_energies: bool = False):
         """Device-resident variant for the fine stage: returns (waves, energies) where ``waves``
         is a CUDA tensor [N,T] of the MEAN-REMOVED candidate outputs (sep/Mic_Array.py:291) that
         stays on the GPU, and ``energies`` the host ndarray [N,2] = (power, power2).  Only the
-        energies (and later the few cluster heads) cross PCIe."""
+        energies (and later the few cluster heads) cross PCIe.  With ``device_energies`` the
+        energies stay on the GPU too and nothing in the call waits for the device (the offsets go
+        up through pinned memory), so the caller can overlap host work with it."""
         import torch
         self._need()
         mix = torch.as_tensor(input_channels)
         offs = offsets_from_patches(patch_list, mix.shape[0] - 1)
         mix_d = mix.to(self.device, dtype=torch.float32).contiguous()
-        off_d = torch.from_numpy(offs).to(self.device)
+        if device_energies:
+            off_d = torch.from_numpy(offs).pin_memory().to(self.device, non_blocking=True)
+        else:
+            off_d = torch.from_numpy(offs).to(self.device)
         wave, en = self.shift_and_sep_device(mix_d, off_d, Strict, want_wave=True, want_energy=True, window=window)
         if wave.shape[0] > 0:
             with torch.cuda.device(self.device):
                 native.check(native.lib().asw_center_rows(native.ptr(wave), wave.shape[0], wave.shape[1],
                                                           native.current_stream()))
-        return wave, en.cpu().numpy()
+        return wave, (en if device_energies else en.cpu().numpy())
 
     def pair_sisdr(self, waves):
         """SI-SDR matrix S[i][j] = si_sdr(est=waves[i], ref=waves[j]) computed on the GPU

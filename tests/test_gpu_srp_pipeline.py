@@ -122,7 +122,9 @@ def test_fine_stage_device_resident_equals_host_path(mic_array, golden):
     for pa, pb in zip(a, b):
         np.testing.assert_array_equal(pa[4]["audio_offset"], pb[4]["audio_offset"])
         np.testing.assert_allclose(pa[4]["localization_offset"], pb[4]["localization_offset"], rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(pa[1], pb[1], rtol=0, atol=1e-6 * max(1.0, np.abs(pb[1]).max()))
+        # the two paths batch the candidates differently (chunks of coarse patches vs one call), and the
+        # GEMM tile shape -- hence the GroupNorm partial-sum order -- follows the batch: 1e-6-level noise
+        np.testing.assert_allclose(pa[1], pb[1], rtol=0, atol=5e-6 * max(1.0, np.abs(pb[1]).max()))
 
 
 def test_search_hip_vs_oracle_north_star_tolerance(mic_array):
