@@ -85,6 +85,7 @@ class MicArray(object):
         self.spotforming_times = 0
         self.big_spotforming_times = 0
         self._device_scorer = None      # set by the fine stage when the spot model offers the GPU SI-SDR kernels
+        self._seg_cache = {}
 
     # ---- stage 1: SRP-PHAT pruning (sep/Mic_Array.py:152-194) ---------------------------
     def Apply_SRP_PHAT(self, mix_data):
@@ -181,8 +182,11 @@ class MicArray(object):
 
         def audio_of(heads):
             return waves_g[heads].cpu().numpy()
-        return self._cluster_group(g, big, patches, list(energies_g[:, 0]), list(energies_g[:, 1]), area, centre,
-                                   T_len, thr_new, sample_gt, sim_of, audio_of)
+        out = self._cluster_group(g, big, patches, list(energies_g[:, 0]), list(energies_g[:, 1]), area, centre,
+                                  T_len, thr_new, sample_gt, sim_of, audio_of)
+        for pair in out:                   # the global clustering needs these; here they hide behind the GPU
+            self._seg_cache[id(pair[1])] = (pair[1], split_wav(pair[1]))
+        return out
 
     def Spotform_Small_Patch_Parallel(self, mix_data, candidate_finished, spot_model, sample_gt=None,
                                       run_demo_folder=None):
@@ -194,6 +198,7 @@ class MicArray(object):
         sharded = getattr(spot_model, "world", 1) > 1
         n_groups = len(candidate_finished)
         self.spotforming_times = 0
+        self._seg_cache = {}               # id(waveform) -> (waveform, voiced segments), filled by the resident path
         if resident and not sharded and n_groups >= 3 and getattr(spot_model, "device", None) is not None:
             return self._fine_stage_pipelined(mix_data, candidate_finished, spot_model, sample_gt, thr_new)
 
@@ -320,7 +325,11 @@ class MicArray(object):
         # one launch for the full-length SI-SDR matrix, one for the segment-wise tensor
         # (SURVEY.md §8f-2).  Any other model keeps the reference's host loops.
         scorer = getattr(self, "_device_scorer", None)
-        seg_all = [split_wav(c[1]) for c in cands]
+        cache = getattr(self, "_seg_cache", {})
+        seg_all = []
+        for c in cands:
+            hit = cache.get(id(c[1]))
+            seg_all.append(hit[1] if hit is not None and hit[0] is c[1] else split_wav(c[1]))
         full_dev = seg_dev = None
         if scorer is not None and len(cands) > 1:
             import torch
