@@ -278,7 +278,7 @@ class MicArray(object):
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=dev)
         side, main = self._side_stream, torch.cuda.current_stream(dev)
-        n_chunks = 3
+        n_chunks = 3                                   # 4-6 chunks measured the same (240-244 ms end to end)
         edges = [round(n_groups * k / n_chunks) for k in range(n_chunks + 1)]
         output_pair, inflight = [], None
 
