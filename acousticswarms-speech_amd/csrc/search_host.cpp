@@ -164,3 +164,31 @@ extern "C" int asw_search_area(const double* points, int n_pts, const double* mi
 }
 
 extern "C" void asw_free(void* p) { std::free(p); }
+
+// Grid points whose TDoA vector lies inside a cube: the box scan of hyperbola_offset /
+// hyperbola_area_sample (sep/Traditional_SP/SRP_Prunning.py:19-61) over a sub-box
+// [y0,y1) x [x0,x1) x all z of a lookup table offsets[ny][nx][nz][P].  Writes the flat indices
+// ((y*nx + x)*nz + z) of the hits in scan order (the order of the reference's boolean mask).
+extern "C" int asw_cube_select(const double* offsets, int ny, int nx, int nz, int P, int y0, int y1, int x0, int x1,
+                               const double* lo, const double* hi, int32_t* out_idx, int64_t cap, int64_t* count) {
+  ASW_CHECK_ARG(offsets && lo && hi && out_idx && count, "cube_select: null pointer");
+  ASW_CHECK_ARG(ny > 0 && nx > 0 && nz > 0 && P > 0 && 0 <= y0 && y0 <= y1 && y1 <= ny && 0 <= x0 && x0 <= x1 && x1 <= nx,
+                "cube_select: bad box");
+  int64_t n = 0;
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      const double* row = offsets + ((size_t)y * nx + x) * nz * P;
+      for (int z = 0; z < nz; ++z) {
+        const double* v = row + (size_t)z * P;
+        bool in = true;
+        for (int p = 0; p < P; ++p)
+          if (!(v[p] >= lo[p] && v[p] <= hi[p])) { in = false; break; }
+        if (in) {
+          if (n >= cap) return asw::set_error(ASW_ERR_ARG, "cube_select: output capacity %lld too small", (long long)cap);
+          out_idx[n++] = (int32_t)(((size_t)y * nx + x) * nz + z);
+        }
+      }
+    }
+  *count = n;
+  return ASW_OK;
+}

@@ -105,6 +105,8 @@ SIGNATURES = {
                                 POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                 POINTER(c_void_p)]),
     "asw_free": (None, [c_void_p]),
+    "asw_cube_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                c_void_p, c_int64, POINTER(c_int64)]),
     "asw_srp_frames": (c_int, [c_int, c_int, c_int]),
     "asw_srp_cross_spectra": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -255,6 +255,13 @@ int asw_search_area(const double* points, int n_pts, const double* mic, int M, d
                     double** child_offset, double** child_width, int** child_count, int** child_index);
 void asw_free(void* p);
 
+/* HOST function (no GPU): flat indices ((y*nx + x)*nz + z), in scan order, of the points of the
+ * sub-box [y0,y1) x [x0,x1) x all z of a TDoA lookup table offsets[ny][nx][nz][P] (float64)
+ * whose every pair offset lies in [lo[p], hi[p]] -- hyperbola_offset / hyperbola_area_sample
+ * (sep/Traditional_SP/SRP_Prunning.py:19-61). */
+int asw_cube_select(const double* offsets, int ny, int nx, int nz, int P, int y0, int y1, int x0, int x1,
+                    const double* lo, const double* hi, int32_t* out_idx, int64_t cap, int64_t* count);
+
 /* SRP-PHAT pruning map (sep/Traditional_SP/SRP_Prunning.py:387-434), two stages.
  *
  * asw_srp_cross_spectra: for each of n_windows analysis windows (start w*step, length
