@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--candidates", type=int, default=256, help="candidates per GPU per step")
     ap.add_argument("--samples", type=int, default=48000, help="T: 48000 = 3 s @ 16 kHz (BASELINE literal)")
-    ap.add_argument("--batch", type=int, default=128, help="internal candidate batch (spot_batch_size)")
+    ap.add_argument("--batch", type=int, default=256, help="internal candidate batch (spot_batch_size)")
     ap.add_argument("--cpu-sample", type=int, default=96, help="candidates timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-library per-kernel event timing")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end pipeline latency measurement")
