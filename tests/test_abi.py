@@ -35,6 +35,31 @@ def test_argument_errors_do_not_need_a_gpu():
     assert b"depth" in L.asw_last_error()
     assert L.asw_convgemm_f32(None, None) == -1
     assert L.asw_spot_shift_and_sep(None, None, 7, 100, None, 1, 0, 1, None, None, 0, None) == -1
+    assert L.asw_segment_sisdr(None, 4, 100, None, None, 2, None, None) == -1
+    assert b"segment_sisdr" in L.asw_last_error()
+    assert L.asw_add_layernorm(None, None, None, None, 4, 1024, 1e-5, None, None) == -1
+
+
+def test_host_entry_points_run_without_a_gpu():
+    """asw_cube_select / asw_search_area are plain host functions of the library."""
+    import numpy as np
+    from ctypes import byref, c_int64, c_void_p
+    L = native.lib()
+    rng = np.random.default_rng(0)
+    off = np.ascontiguousarray(rng.uniform(-10, 10, (5, 7, 3, 4)))
+    c, w = np.array([1.0, -2.0, 0.5, 3.0]), 9.0
+    lo, hi = np.ascontiguousarray(c - w / 2), np.ascontiguousarray(c + w / 2)
+    idx = np.empty(5 * 7 * 3, dtype=np.int32)
+    n = c_int64()
+    native.check(L.asw_cube_select(c_void_p(off.ctypes.data), 5, 7, 3, 4, 1, 4, 2, 6, c_void_p(lo.ctypes.data),
+                                   c_void_p(hi.ctypes.data), c_void_p(idx.ctypes.data), idx.size, byref(n)))
+    mask = np.zeros((5, 7, 3), dtype=bool)
+    mask[1:4, 2:6] = np.all((off[1:4, 2:6] >= lo) & (off[1:4, 2:6] <= hi), axis=-1)
+    np.testing.assert_array_equal(idx[:n.value], np.flatnonzero(mask))
+    # capacity too small -> status + message, no overrun
+    assert L.asw_cube_select(c_void_p(off.ctypes.data), 5, 7, 3, 4, 0, 5, 0, 7, c_void_p((c - 100).ctypes.data),
+                             c_void_p((c + 100).ctypes.data), c_void_p(idx.ctypes.data), 3, byref(n)) == -1
+    assert b"capacity" in L.asw_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
