@@ -12,6 +12,15 @@ int set_error(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+int SmemAttr::ensure(const void* kern, size_t want) {
+  int dev = 0;
+  ASW_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDev) return set_error(ASW_ERR_ARG, "device ordinal %d out of range", dev);
+  if (bytes[dev] >= want) return ASW_OK;
+  ASW_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+  bytes[dev] = want;
+  return ASW_OK;
+}
 }  // namespace asw
 
 extern "C" const char* asw_last_error(void) { return asw::err_buf(); }

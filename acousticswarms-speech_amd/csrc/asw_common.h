@@ -36,6 +36,15 @@ int set_error(int code, const char* fmt, ...);
   } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel.  One
+// SmemAttr per launch site remembers the largest size already set on each device, so a process
+// that serves several GPUs (SpotModel.to("cuda:1"), one stream per device) sets it on each.
+struct SmemAttr {
+  static constexpr int kMaxDev = 64;
+  size_t bytes[kMaxDev] = {};
+  int ensure(const void* kern, size_t want);     // 0 or a negative asw_status
+};
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace asw

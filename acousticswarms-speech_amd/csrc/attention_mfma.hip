@@ -277,12 +277,8 @@ int attention_mfma(const float* qkv, int B, int L, int d, int nhead, float* ctx,
     const int LP64 = cdiv(L, BK) * BK;
     const size_t smem64 = sizeof(float) * ((size_t)BQ * LDQ + (size_t)BK * LDQ + (size_t)BQ * (LP64 + 4));
     if (smem64 <= 160 * 1024 && (long)L * 3 * d * 4 < (1L << 31)) {
-      static size_t attr64 = 0;
-      if (smem64 > attr64) {
-        ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma64_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64));
-        attr64 = smem64;
-      }
+      static SmemAttr attr64;                           // per device
+      if (int rc = attr64.ensure(reinterpret_cast<const void*>(attention_mfma64_kernel), smem64)) return rc;
       dim3 grid(cdiv(L, BQ), nhead, B);
       ProfScope prof(s, "attention_mfma64", 4.0 * B * nhead * (double)L * L * AD);
       hipLaunchKernelGGL(attention_mfma64_kernel, grid, dim3(256), smem64, s, qkv, L, LP64, d, ctx);
@@ -293,12 +289,8 @@ int attention_mfma(const float* qkv, int B, int L, int d, int nhead, float* ctx,
   if ((long)L * 3 * d * 4 < (1L << 31)) {
     // long sequences: key-tiled two-pass kernel (any L)
     constexpr size_t smemf = sizeof(float) * ((size_t)BQ * LDQ + (size_t)BK * LDQ + (size_t)BQ * (BK + 4) + 2 * BQ);
-    static bool attrf = false;
-    if (!attrf) {
-      ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_flash_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemf));
-      attrf = true;
-    }
+    static SmemAttr attrf;                              // per device
+    if (int rc = attrf.ensure(reinterpret_cast<const void*>(attention_mfma_flash_kernel), smemf)) return rc;
     dim3 grid(cdiv(L, BQ), nhead, B);
     ProfScope prof(s, "attention_mfma_flash", 4.0 * B * nhead * (double)L * L * AD);
     hipLaunchKernelGGL(attention_mfma_flash_kernel, grid, dim3(256), smemf, s, qkv, L, d, ctx);

@@ -658,12 +658,8 @@ int launch_res(const asw_convgemm_args& a, hipStream_t s) {
   const size_t smem = img > slab ? img : slab;
   if (smem > 160 * 1024) return 1;                     // caller falls back to the generic kernel
   auto kern = resconv16_kernel<BM, C, WM, WN, PH, QD>;
-  static bool attr = false;
-  if (!attr) {
-    ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    attr = true;
-  }
+  static asw::SmemAttr attr;                            // per device
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
   const int gx = PH == 1 ? asw::cdiv(a.M_out, BM)
                          : asw::cdiv(asw::cdiv(a.M_out, a.dil), BMJ) * asw::cdiv(a.dil, PH);
   dim3 grid(gx, 1, a.B);
@@ -724,11 +720,8 @@ int launch(const asw_convgemm_args& a, hipStream_t s) {
   const void* kern;
   if constexpr (F16) kern = reinterpret_cast<const void*>(convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>);
   else kern = reinterpret_cast<const void*>(convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>);
-  static bool attr_set = false;
-  if (!attr_set) {
-    ASW_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  static asw::SmemAttr attr;                            // per device
+  if (int rc = attr.ensure(kern, smem)) return rc;
   ASW_CHECK_ARG(A2F == (a.A2 != nullptr), "convgemm: the skip operand is fused only in the 128-wide statistics tile");
   ASW_CHECK_ARG(a.Cin % BK == 0, "convgemm: Cin=%d not a multiple of BK=%d", a.Cin, BK);
   ASW_CHECK_ARG(a.N % BN == 0, "convgemm: N=%d not a multiple of BN=%d", a.N, BN);

@@ -459,12 +459,8 @@ extern "C" int asw_attention(const float* qkv, int B, int L, int d, int nhead, f
   ASW_CHECK_ARG(B <= 65535 && nhead <= 65535, "attention: grid too large");
   const size_t smem = sizeof(float) * ((size_t)ATT_BQ * (hd + 1) + (size_t)ATT_KT * (hd + 1) + (size_t)ATT_KT * hd +
                                        (size_t)ATT_BQ * ATT_KT);
-  static size_t smem_set = 0;
-  if (smem > smem_set) {
-    ASW_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    smem_set = smem;
-  }
+  static asw::SmemAttr smem_attr;                      // per device
+  if (int rc = smem_attr.ensure(reinterpret_cast<const void*>(attention_kernel), smem)) return rc;
   dim3 grid(asw::cdiv(L, ATT_BQ), nhead, B);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(256), smem, asw::as_stream(stream), qkv, L, d, nhead, ctx);
   ASW_LAUNCH_CHECK();

@@ -97,6 +97,7 @@ struct GateSet {
   std::vector<std::unique_ptr<WBuf>> down_wt;   // per encoder block
   std::vector<std::unique_ptr<WBuf>> up_wt;     // per decoder block
   std::vector<std::unique_ptr<DevBuf>> up_bias;
+  uint64_t stamp = 0;                           // last use (LRU eviction)
 };
 struct Tap { const float* p; size_t numel; };
 
@@ -107,6 +108,8 @@ struct asw_spot {
   std::map<std::string, std::vector<float>> raw;
   bool finalized = false;
   int batch = 32;
+  int device = 0;                          // HIP device the weights and the workspace live on
+  uint64_t clock = 0;
 
   // derived
   std::vector<int> enc_cin, enc_cout;      // per encoder block
@@ -242,9 +245,17 @@ std::vector<float> gate_of(const std::vector<float>& w, const std::vector<float>
 int get_gates(asw_spot* m, float w0, float w1, GateSet** out) {
   auto key = std::make_pair(w0, w1);
   auto it = m->gates.find(key);
-  if (it != m->gates.end()) { *out = it->second.get(); return ASW_OK; }
-  if (m->gates.size() >= 8) m->gates.clear();          // bounded cache
+  if (it != m->gates.end()) { it->second->stamp = ++m->clock; *out = it->second.get(); return ASW_OK; }
+  if (m->gates.size() >= 8) {
+    // bounded cache: drop the least recently used set.  Launches that read it may still be queued;
+    // its buffers are released with hipFree, which waits for the device, so they finish first.
+    auto lru = m->gates.begin();
+    for (auto g = m->gates.begin(); g != m->gates.end(); ++g)
+      if (g->second->stamp < lru->second->stamp) lru = g;
+    m->gates.erase(lru);
+  }
   std::unique_ptr<GateSet> gs(new GateSet());
+  gs->stamp = ++m->clock;
   const asw_spot_config& c = m->cfg;
   for (int i = 0; i < c.depth; ++i) {
     const std::string p = "encoder.module_list." + std::to_string(i);
@@ -496,6 +507,10 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
 int check_ready(const asw_spot* m) {
   if (!m) return asw::set_error(ASW_ERR_ARG, "null model handle");
   if (!m->finalized) return asw::set_error(ASW_ERR_STATE, "asw_spot_finalize() has not been called");
+  int dev = -1;
+  ASW_HIP(hipGetDevice(&dev));
+  if (dev != m->device)
+    return asw::set_error(ASW_ERR_STATE, "model lives on HIP device %d but the current device is %d", m->device, dev);
   return ASW_OK;
 }
 
@@ -517,6 +532,7 @@ extern "C" int asw_spot_create(const asw_spot_config* cfg, asw_spot** out) {
   ASW_CHECK_ARG(c.ffw_dim % 128 == 0, "spot_create: ffw_dim must be a multiple of 128");
   std::unique_ptr<asw_spot> m(new asw_spot());
   m->cfg = c;
+  ASW_HIP(hipGetDevice(&m->device));
   int cin = c.channels, ch = c.channels;
   for (int i = 0; i < c.depth; ++i) {
     ASW_CHECK_ARG(c.stride_list[i] >= 1, "spot_create: stride");
@@ -569,6 +585,12 @@ extern "C" int asw_spot_set_param(asw_spot* m, const char* key, const float* hos
 
 extern "C" int asw_spot_finalize(asw_spot* m) {
   ASW_CHECK_ARG(m, "finalize: null handle");
+  {
+    int dev = -1;
+    ASW_HIP(hipGetDevice(&dev));
+    if (dev != m->device)
+      return asw::set_error(ASW_ERR_STATE, "finalize: model was created on HIP device %d, current device is %d", m->device, dev);
+  }
   const asw_spot_config& c = m->cfg;
   const auto want = expected_params(m);
   for (const auto& kv : want) {

@@ -86,6 +86,10 @@ class MicArray(object):
         self.big_spotforming_times = 0
         self._device_scorer = None      # set by the fine stage when the spot model offers the GPU SI-SDR kernels
         self._seg_cache = {}
+        # decision trace of the latest search (cheap bookkeeping, used by the precision flip-rate and
+        # parity tests): coarse kept indices, per coarse patch {head: members} of the fine-stage
+        # clustering, and the global clusters as lists of "g_head" names
+        self.trace = {"coarse_kept": [], "fine_clusters": {}, "final_clusters": []}
 
     # ---- stage 1: SRP-PHAT pruning (sep/Mic_Array.py:152-194) ---------------------------
     def Apply_SRP_PHAT(self, mix_data):
@@ -104,6 +108,8 @@ class MicArray(object):
         kept, _powers_with_dis, rel_thr = binary_search_baseline(mix_data, spot_model, patch_list,
                                                                  self.mic_positions)
         self.Relative_Threshold = rel_thr
+        pos = {id(p): i for i, p in enumerate(patch_list)}
+        self.trace = {"coarse_kept": [pos[id(p)] for p in kept], "fine_clusters": {}, "final_clusters": []}
         return kept
 
     # ---- stage 3: fine Spotforming, strict window (sep/Mic_Array.py:225-395) ------------
@@ -153,6 +159,7 @@ class MicArray(object):
                 clusters[k] = [k]
             else:
                 clusters[home].append(k)
+        self.trace["fine_clusters"][int(g)] = {int(h): [int(k) for k in m] for h, m in clusters.items()}
         if len(clusters) == 0:
             return out
         heads = list(clusters.keys())
@@ -374,6 +381,7 @@ class MicArray(object):
                     delta = (cands[h][-2]["audio_offset"] - sample_gt[:, big_label]).astype(int)
                     wrong.append((big_label, cands[h][-1], delta, power1 / cands[h][2]))
         print("final speaker number is ", len(clusters.keys()))
+        self.trace["final_clusters"] = [[cands[i][3] for i in clusters[h]] for h in clusters]
         patch_final = [cands[clusters[h][0]] for h in clusters]
         audio_final = [p[1] for p in patch_final]
         return audio_final, patch_final, self.big_spotforming_times + self.spotforming_times, wrong

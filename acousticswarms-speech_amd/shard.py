@@ -36,6 +36,32 @@ def shard_groups(sizes: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(o) for o in owner]
 
 
+def offsets_fingerprint(patches_or_offsets) -> int:
+    """CRC32 of the rounded int32 offsets of a candidate list (ndarray [N,P] or patches)."""
+    import zlib
+    if len(patches_or_offsets) == 0:
+        return 0
+    offs = np.stack([np.asarray(getattr(p, "sample_offset", p), dtype=np.float64) for p in patches_or_offsets])
+    return zlib.crc32(np.ascontiguousarray(np.rint(offs.astype(np.float32)).astype(np.int32)).tobytes())
+
+
+def assert_same_on_all_ranks(dist, group, device, what: str, *values: int):
+    """Every rank derives shard widths and group ownership locally from its own (deterministic)
+    host search.  If the ranks ever disagreed -- another candidate count, other group sizes,
+    other offsets -- the fixed-shape exchange that follows would hang or silently mis-assemble
+    the energies.  So each exchange is preceded by an all-gather of this small fingerprint and
+    a mismatch raises on every rank."""
+    import torch
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    box = torch.empty((world * len(values),), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(box, mine, group=group)
+    box = box.view(world, len(values)).cpu()
+    if not bool((box == box[0:1]).all()):
+        raise RuntimeError(f"ranks disagree before the {what} exchange (per-rank fingerprints {box.tolist()}): "
+                           "the candidate lists are not identical on every rank")
+
+
 class ShardedScorer:
     """score(mix, offsets[N,P]) -> energies [N,2] on every rank.
 
@@ -61,6 +87,7 @@ class ShardedScorer:
             return local.cpu().numpy().reshape(N, 2)
         width = max(b[r + 1] - b[r] for r in range(self.world))     # pad to equal shards
         dev = device if device is not None else local.device
+        assert_same_on_all_ranks(self.dist, self.group, dev, "energy", N, offsets_fingerprint(offsets))
         buf = torch.zeros((width, 2), dtype=torch.float64, device=dev)
         buf[:hi - lo] = local.to(dev)
         out = torch.empty((self.world * width, 2), dtype=torch.float64, device=dev)
@@ -139,6 +166,9 @@ class ShardedSpotModel:
         sizes = [bounds[i + 1] - bounds[i] for i in range(len(bounds) - 1)]
         owners = shard_groups(sizes, self.world)
         width = max(1, max(sum(sizes[g] for g in o) for o in owners))
+        import zlib
+        assert_same_on_all_ranks(self.dist, self.group, self.device, "fine-stage energy", len(sizes), int(bounds[-1]),
+                                 zlib.crc32(np.asarray(sizes, dtype=np.int64).tobytes()))
         buf = torch.zeros((width, 2), dtype=torch.float64, device=self.device)
         loc = torch.as_tensor(np.asarray(local_energies, dtype=np.float64).reshape(-1, 2))
         buf[:loc.shape[0]] = loc.to(self.device)

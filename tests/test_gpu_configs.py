@@ -1,0 +1,236 @@
+"""GPU: the BASELINE.json configurations that had no HIP-path test in round 1.
+
+configs[2]  5-speaker reverberant mixture, 7 mics: the complete search with the HIP spot model
+            against the CPU oracle behind the reference's shift_and_sep surface (T = 24 000 so the
+            oracle finishes in minutes), plus the joint separation stage on the talkers found.
+configs[3]  a batch of 5-speaker mixtures: shard.localize_batch with the HIP model equals the
+            plain per-mixture loop, in one process and with two ranks sharing this box's GPU.
+flip rate   f16x3 (the bench arithmetic) against exact f32 on 16 full-size scenes (seeds
+            1001-1008 three talkers, 1010-1017 five talkers + reverb, T = 48 000): every hard
+            decision of the search -- coarse kept set, fine-stage accept / cluster membership,
+            global clusters, final talkers -- compared; the counts go to
+            gpurun_out/flip_rate_f16x3.json (thresholds: sep/helpers/constants.py:35-41,
+            sep/Mic_Array.py:333-348,401).
+Needs an MI355X."""
+import io
+import json
+import os
+import socket
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _log(msg):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "diag_configs.txt"), "a") as f:
+        f.write(msg + "\n")
+    print(msg)
+
+
+@pytest.fixture(scope="module")
+def full_weights():
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    return make_spot_state_dict(FULL, 5)
+
+
+def _search(jm, mix_t):
+    with redirect_stdout(io.StringIO()):
+        patches, audio_loc, audio, _, _, spot_times = jm.forward(mix_t)
+    tr = jm.Mic_processor.trace
+    return patches, audio_loc, audio, spot_times, {"coarse_kept": list(tr["coarse_kept"]),
+                                                   "fine_clusters": {g: dict(c) for g, c in tr["fine_clusters"].items()},
+                                                   "final_clusters": [list(c) for c in tr["final_clusters"]]}
+
+
+# ------------------------------------------------------------------------------ configs[2]
+def test_config2_five_speaker_reverb_search_vs_oracle(full_weights):
+    """The north-star tolerance on the 5-speaker reverberant scene: same talkers, <= 2 cm,
+    waveforms >= 60 dB from the oracle's (0.1 dB of SI-SDR corresponds to ~50 dB)."""
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.hostdsp import si_sdr
+    from acousticswarms_speech_amd.joint import JointModel
+    from acousticswarms_speech_amd.scenes import make_scene
+    from acousticswarms_speech_amd.spot import SpotModel
+    from oracle import spot_ref
+    sd = full_weights
+    sc = make_scene(1010, 5, 7, 24000, reverb=True)
+    mix_t = torch.from_numpy(sc.mix)
+
+    class OracleSpot:                      # the reference surface, computed by oracle/spot_ref.py on the CPU
+        def shift_and_sep(self, m, patch_list, Strict=0, save_input=False):
+            if len(patch_list) == 0:
+                return np.empty((0, m.shape[1]), dtype=np.float32)
+            return spot_ref.shift_and_sep(sd, FULL, m, [p.sample_offset for p in patch_list], strict=Strict,
+                                          batch_size=8)
+
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    res = {}
+    for name, spot in (("hip", SpotModel(FULL, sd, batch_size=64, precision="f16x3").to("cuda")),
+                       ("oracle", OracleSpot())):
+        jm = JointModel(spot, None, device="cuda")
+        with redirect_stdout(io.StringIO()):
+            jm.setup(sc.mic_positions, sc.speaker_range)
+        res[name] = _search(jm, mix_t) + (list(jm.times),)
+    (ph, ah, _x, nh, trh, th), (po, ao, _y, no, tro, to) = res["hip"], res["oracle"]
+    _log(f"config2: talkers hip={len(ph)} oracle={len(po)}, spot calls {nh}/{no}, stage s hip={np.round(th, 3)} "
+         f"oracle={np.round(to, 1)}")
+    assert nh == no and len(ph) == len(po) and len(ph) >= 1
+    assert trh == tro                                                   # every hard decision identical
+    assert [p[3] for p in ph] == [p[3] for p in po]
+    err_cm = [100 * float(np.linalg.norm(a[0].center_pos() - b[0].center_pos())) for a, b in zip(ph, po)]
+    sdr = [si_sdr(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)) for a, b in zip(ah, ao)]
+    _log(f"config2: position error cm {np.round(err_cm, 4)}, SI-SDR(hip, oracle) dB {np.round(sdr, 1)}")
+    assert max(err_cm) <= 2.0
+    assert min(sdr) >= 60.0
+
+
+# ------------------------------------------------------------------------------ configs[3]
+def _batch_scenes(n, T=24000):
+    from acousticswarms_speech_amd.scenes import make_scene
+    first = make_scene(2000, 5, 7, T)
+    return first, [make_scene(2000 + k, 5, 7, T, mic_positions=first.mic_positions) for k in range(n)]
+
+
+def _batch_summary(out):
+    return [(r["centres"], r["powers"], list(r["names"]), int(r["spot_times"])) for r in out]
+
+
+def _batch_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from acousticswarms_speech_amd.config import FULL
+        from acousticswarms_speech_amd.joint import JointModel
+        from acousticswarms_speech_amd.shard import localize_batch
+        from acousticswarms_speech_amd.spot import SpotModel
+        from acousticswarms_speech_amd.weights import make_spot_state_dict
+        first, scenes = _batch_scenes(4)
+        jm = JointModel(SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=64, precision="f16x3").to("cuda"),
+                        None, device="cuda")
+        with redirect_stdout(io.StringIO()):
+            jm.setup(first.mic_positions, first.speaker_range)
+            out = localize_batch(jm, [torch.from_numpy(s.mix) for s in scenes])
+        q.put((rank, _batch_summary(out)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config3_mixture_batch_equals_plain_loop(full_weights):
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.joint import JointModel
+    from acousticswarms_speech_amd.shard import localize_batch
+    from acousticswarms_speech_amd.spot import SpotModel
+    import torch.multiprocessing as mp
+    first, scenes = _batch_scenes(4)
+    mixes = [torch.from_numpy(s.mix) for s in scenes]
+    jm = JointModel(SpotModel(FULL, full_weights, batch_size=64, precision="f16x3").to("cuda"), None, device="cuda")
+    with redirect_stdout(io.StringIO()):
+        jm.setup(first.mic_positions, first.speaker_range)
+        got = _batch_summary(localize_batch(jm, mixes))
+        want = []
+        for m in mixes:                                                  # the plain loop: one forward per mixture
+            patches, _al, _a, _d0, _d1, st = jm.forward(m)
+            want.append((np.array([p[0].center_pos() for p in patches]).reshape(-1, 3),
+                         np.array([p[2] for p in patches]), [p[3] for p in patches], int(st)))
+    assert len(got) == 4
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g[0], w[0])
+        np.testing.assert_array_equal(g[1], w[1])
+        assert g[2] == w[2] and g[3] == w[3]
+    _log(f"config3: 4 mixtures, talkers {[len(g[2]) for g in got]}, spot calls {[g[3] for g in got]}")
+    del jm
+    torch.cuda.empty_cache()
+    # two ranks (sharing this box's one GPU; gloo carries the object all-gather): mixtures split 2 + 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _rank, out in res:
+        assert len(out) == 4
+        for g, w in zip(out, got):
+            np.testing.assert_allclose(g[0], w[0], atol=1e-9)
+            np.testing.assert_allclose(g[1], w[1], rtol=1e-6)
+            assert g[2] == w[2] and g[3] == w[3]
+
+
+# ------------------------------------------------------------------------------ flip rate
+def _count_flips(a, b):
+    """Differences between two decision traces."""
+    coarse = len(set(a["coarse_kept"]) ^ set(b["coarse_kept"])) + int(a["coarse_kept"] != b["coarse_kept"]
+                                                                      and set(a["coarse_kept"]) == set(b["coarse_kept"]))
+    accept = members = 0
+    for g in set(a["fine_clusters"]) | set(b["fine_clusters"]):
+        ca, cb = a["fine_clusters"].get(g, {}), b["fine_clusters"].get(g, {})
+        acc_a = {k for m in ca.values() for k in m}
+        acc_b = {k for m in cb.values() for k in m}
+        accept += len(acc_a ^ acc_b)
+        owner_a = {k: h for h, m in ca.items() for k in m}
+        owner_b = {k: h for h, m in cb.items() for k in m}
+        members += sum(1 for k in acc_a & acc_b if owner_a[k] != owner_b[k])
+    final = int(sorted(map(tuple, a["final_clusters"])) != sorted(map(tuple, b["final_clusters"])))
+    return {"coarse": coarse, "fine_accept": accept, "fine_membership": members, "final": final}
+
+
+def test_f16x3_flip_rate_full_size(full_weights):
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.joint import JointModel
+    from acousticswarms_speech_amd.scenes import make_scene
+    from acousticswarms_speech_amd.spot import SpotModel
+    spot = SpotModel(FULL, full_weights, batch_size=128, precision="f32").to("cuda")
+    jm = JointModel(spot, None, device="cuda")
+    rows, tot = [], {"coarse": 0, "fine_accept": 0, "fine_membership": 0, "final": 0}
+    n_coarse = n_fine = 0
+    worst_cm = 0.0
+    for seed in list(range(1001, 1009)) + list(range(1010, 1018)):
+        five = seed >= 1010
+        sc = make_scene(seed, 5 if five else 3, 7, 48000, reverb=five)
+        mix_t = torch.from_numpy(sc.mix)
+        with redirect_stdout(io.StringIO()):
+            jm.setup(sc.mic_positions, sc.speaker_range)
+        out = {}
+        for prec in ("f32", "f16x3"):
+            spot.set_precision(prec)
+            patches, audio_loc, _a, spot_times, tr = _search(jm, mix_t)
+            assert np.all(np.isfinite(audio_loc)) if len(patches) else True
+            out[prec] = (patches, spot_times, tr, jm.Mic_processor.big_spotforming_times)
+        (p32, n32, t32, c32), (p16, n16, t16, _c) = out["f32"], out["f16x3"]
+        fl = _count_flips(t32, t16)
+        n_coarse += c32
+        n_fine += n32 - c32
+        if fl["final"] == 0 and len(p32):
+            worst_cm = max(worst_cm, max(100 * float(np.linalg.norm(a[0].center_pos() - b[0].center_pos()))
+                                         for a, b in zip(p32, p16)))
+        for k in tot:
+            tot[k] += fl[k]
+        rows.append({"seed": seed, "speakers": 5 if five else 3, "reverb": five, "spot_calls_f32": int(n32),
+                     "spot_calls_f16x3": int(n16), "talkers_f32": len(p32), "talkers_f16x3": len(p16), "flips": fl})
+    rec = {"what": "hard-decision differences of the complete search, f16x3 vs exact f32 MFMA, same seeded FULL weights, "
+                   "T=48000", "scenes": len(rows), "coarse_candidates": int(n_coarse), "fine_candidates": int(n_fine),
+           "flips_total": tot,
+           "flip_rate_per_candidate": (tot["coarse"] + tot["fine_accept"] + tot["fine_membership"]) / max(1, n_coarse + n_fine),
+           "worst_position_difference_cm": worst_cm, "per_scene": rows}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "flip_rate_f16x3.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    _log(f"flip rate: {rec['scenes']} scenes, {n_coarse} coarse + {n_fine} fine candidates, flips {tot}, "
+         f"worst position difference {worst_cm:.4f} cm")
+    assert tot["final"] == 0 and tot["coarse"] == 0
+    assert rec["flip_rate_per_candidate"] <= 1e-3
+    assert worst_cm <= 2.0

@@ -204,3 +204,38 @@ def test_two_rank_mixture_batch_matches_single_process():
             assert got[2] == w["names"] and got[3] == w["spot_times"]
     # rank 0 ran two mixtures, rank 1 one (2 spot calls per mixture: coarse + fine)
     assert [n for _r, _o, n in res] == [4, 2]
+
+
+# ---------------------------------------------------------------- ranks that disagree
+def _diverging_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        offs = np.random.default_rng(3).integers(-100, 100, size=(9, 6)).astype(np.int32)
+        if rank == 1:
+            offs = offs.copy()
+            offs[4, 2] += 1                       # one candidate differs on this rank
+        try:
+            ShardedScorer(_fake_score).score(None, offs, device="cpu")
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_diverging_candidate_lists_raise_on_every_rank():
+    """The fixed-shape energy exchange assumes identical candidate lists on all ranks; a
+    divergence must be detected (fingerprint all-gather) instead of mis-assembling energies."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_diverging_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _rank, msg in res:
+        assert "ranks disagree" in msg
