@@ -14,7 +14,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .config import SpotConfig, spot_param_shapes
+from .config import SepConfig, SpotConfig, sep_param_shapes, spot_param_shapes
 
 
 def _tensor(seed: int, index: int, shape, kind: str) -> np.ndarray:
@@ -54,6 +54,27 @@ def make_spot_state_dict(cfg: SpotConfig, seed: int = 0) -> "OrderedDict[str, np
     sd = OrderedDict()
     for i, (name, shape) in enumerate(spot_param_shapes(cfg)):
         sd[name] = _tensor(seed, i, shape, _kind(name))
+    return sd
+
+
+def make_sep_state_dict(cfg: SepConfig, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded float32 state dict of the joint separation network (reference key names for the
+    U-Net / mask path, published speechbrain names for the Conformer, config.sep_param_shapes)."""
+    import math as _m
+    sd = OrderedDict()
+    for i, (name, shape) in enumerate(sep_param_shapes(cfg)):
+        if name.endswith("pe_single.inv_freq"):
+            d = 2 * shape[0]              # RelPosEncXL: exp(arange(0, d, 2) * -(ln 10000 / d)), float32
+            sd[name] = np.exp(np.arange(0, d, 2, dtype=np.float32) * np.float32(-(_m.log(10000.0) / d))).astype(np.float32)
+            continue
+        kind = _kind(name)
+        if "pos_bias_" in name:
+            kind = "bias"
+        elif name.endswith("in_proj_weight") or name.endswith("linear_pos.weight"):
+            kind = "weight"
+        elif name.endswith("weight") and len(shape) == 1:      # every LayerNorm / GroupNorm scale
+            kind = "norm_w"
+        sd[name] = _tensor(seed + 7919, i, shape, kind)
     return sd
 
 
