@@ -1,0 +1,471 @@
+// sep_kernels.hip -- the small (memory / latency bound, VALU) kernels of the joint separation
+// network: joint normalisation statistics of the S x M zero-fill-shifted channels
+// (sep/training/SpeakerSeparation/network.py:510-534 with :28-40) and the pieces of its
+// bottleneck (:270-321) that are not GEMMs -- row LayerNorms with fused residual adds, GLU,
+// depthwise convolution + LayerNorm + Swish, relative-position self-attention over time
+// (speechbrain RelPosMHAXL as published; the library itself is absent, see oracle/sep_ref.py)
+// and the inter-speaker attention over the S speakers of one time step
+// (nn.TransformerEncoderLayer, :290-291,311-316).
+//
+// The bottleneck tensors are [S][L][d] fp32 channels-last with L = T/64 (750 at T = 48 000),
+// d = 512: a few MB, so every kernel here is one short pass and the stage is launch-latency
+// bound; the GEMMs between them run on the MFMA kernels of convgemm.hip.
+#include "asw_common.h"
+
+namespace {
+
+__device__ __forceinline__ float quant16(float x) { return rintf(x * 32768.0f) * (1.0f / 32768.0f); }
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wsum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float swishf(float v) { return v / (1.0f + expf(-v)); }
+
+// ---------------------------------------------------------------------------------------
+// Joint statistics: ref[t] = mean over the S*M channels of the int16-quantised, zero-fill
+// shifted mixture (channel (s,m) = mix[m] advanced by offsets[s][m-1], mic 0 unshifted);
+// mean = mean_t ref, std = unbiased std_t ref.  Pass 1: per-block partial (sum, sum of
+// squares) in double over a strided set of samples; pass 2: one wave reduces the partials and
+// writes S copies (the preproc / un-normalise kernels take per-sequence arrays).
+// ---------------------------------------------------------------------------------------
+constexpr int JS_MAXCH = 2048;
+constexpr int JS_BLOCKS = 128;
+
+__global__ __launch_bounds__(256) void joint_stats_partial_kernel(const float* __restrict__ mix, int M, int T,
+                                                                  const int32_t* __restrict__ offsets, int S,
+                                                                  double* __restrict__ part) {
+  __shared__ int off[JS_MAXCH];
+  __shared__ double red[4][2];
+  const int SM = S * M;
+  for (int i = threadIdx.x; i < SM; i += 256) {
+    const int s = i / M, m = i - s * M;
+    off[i] = m == 0 ? 0 : offsets[(long)s * (M - 1) + m - 1];
+  }
+  __syncthreads();
+  double a0 = 0.0, a1 = 0.0;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s)
+      for (int m = 0; m < M; ++m) {
+        const int i = t + off[s * M + m];
+        const float x = (i >= 0 && i < T) ? mix[(long)m * T + i] : 0.f;
+        acc += quant16(x);
+      }
+    const float r = acc / (float)SM;
+    a0 += (double)r;
+    a1 += (double)r * (double)r;
+  }
+  a0 = wsum_d(a0); a1 = wsum_d(a1);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { red[wid][0] = a0; red[wid][1] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2 + 0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    part[blockIdx.x * 2 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  }
+}
+
+__global__ __launch_bounds__(64) void joint_stats_final_kernel(const double* __restrict__ part, int nblocks, int T, int S,
+                                                               float* __restrict__ mean_out, float* __restrict__ std_out) {
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { a0 += part[i * 2]; a1 += part[i * 2 + 1]; }
+  a0 = wsum_d(a0); a1 = wsum_d(a1);
+  const double mean = a0 / (double)T;
+  double var = (a1 - a0 * a0 / (double)T) / (double)(T - 1);      // Bessel, torch.std default
+  if (var < 0) var = 0;
+  const float mu = (float)mean, sg = (float)sqrt(var);
+  for (int s = threadIdx.x; s < S; s += 64) { mean_out[s] = mu; std_out[s] = sg; }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row kernel: s = x + alpha * y (y optional); sum_out = s (optional);
+// ln_out = act(LayerNorm(s) * gamma + beta) (optional; act 0 = none, 2 = Swish).
+// One wave per row, the row in registers (NV float4 per lane, N <= 256 * NV, N % 4 == 0),
+// two-pass statistics by wave shuffles -- the arithmetic of the GEMM epilogue's LayerNorm.
+// ---------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void add_ln2_kernel(const float* __restrict__ x, const float* __restrict__ y, float alpha,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int rows, int N, float eps, int act, float* __restrict__ sum_out,
+                                                      float* __restrict__ ln_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int n4 = N >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (long)row * N);
+  const float4* yr = y ? reinterpret_cast<const float4*>(y + (long)row * N) : nullptr;
+  float4 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = i * 64 + lane;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < n4) {
+      a = xr[c4];
+      if (yr) { const float4 b = yr[c4]; a.x += alpha * b.x; a.y += alpha * b.y; a.z += alpha * b.z; a.w += alpha * b.w; }
+      if (sum_out) reinterpret_cast<float4*>(sum_out + (long)row * N)[c4] = a;
+    }
+    v[i] = a;
+    sum += (a.x + a.y) + (a.z + a.w);
+  }
+  if (!ln_out) return;
+  const float mu = wsum(sum) / (float)N;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (i * 64 + lane < n4) {
+      const float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+      sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wsum(sq) / (float)N + eps);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float4* orow = reinterpret_cast<float4*>(ln_out + (long)row * N);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = i * 64 + lane;
+    if (c4 < n4) {
+      const float4 g = g4[c4], b = b4[c4];
+      float4 o = make_float4((v[i].x - mu) * rstd * g.x + b.x, (v[i].y - mu) * rstd * g.y + b.y,
+                             (v[i].z - mu) * rstd * g.z + b.z, (v[i].w - mu) * rstd * g.w + b.w);
+      if (act == 2) { o.x = swishf(o.x); o.y = swishf(o.y); o.z = swishf(o.z); o.w = swishf(o.w); }
+      orow[c4] = o;
+    }
+  }
+}
+
+// out[r][c] = raw[r][c] * sigmoid(raw[r][C + c])   (nn.GLU over channels-last rows of 2C)
+__global__ __launch_bounds__(256) void glu_rows_kernel(const float* __restrict__ raw, long rows, int C, float* __restrict__ out) {
+  const int c4n = C >> 2;
+  const long total = rows * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(raw + r * 2 * C + c);
+    const float4 g = *reinterpret_cast<const float4*>(raw + r * 2 * C + C + c);
+    float4 o;
+    o.x = a.x / (1.0f + expf(-g.x)); o.y = a.y / (1.0f + expf(-g.y));
+    o.z = a.z / (1.0f + expf(-g.z)); o.w = a.w / (1.0f + expf(-g.w));
+    *reinterpret_cast<float4*>(out + r * C + c) = o;
+  }
+}
+
+// Depthwise Conv1d(d, d, k, padding (k-1)/2, groups = d) over time within each sequence,
+// + bias, then LayerNorm over channels and Swish (ConvolutionModule: conv -> after_conv[0..1]).
+// u, out: [BS][L][d]; wT: [K][d] (tap-major so a wave reads contiguous channel rows).
+// One wave per (sequence, time) row.
+template <int NV>
+__global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const float* __restrict__ u, const float* __restrict__ wT,
+                                                              const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int BS, int L, int d, int K,
+                                                              float eps, float* __restrict__ out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)BS * L) return;
+  const int seq = (int)(row / L), t = (int)(row - (long)seq * L);
+  const int n4 = d >> 2, pad = (K - 1) / 2;
+  float4 acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = i * 64 + lane;
+    acc[i] = c4 < n4 ? reinterpret_cast<const float4*>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int k = 0; k < K; ++k) {
+    const int tt = t + k - pad;
+    if (tt < 0 || tt >= L) continue;                     // wave-uniform: zero padding
+    const float4* ur = reinterpret_cast<const float4*>(u + ((long)seq * L + tt) * d);
+    const float4* wr = reinterpret_cast<const float4*>(wT + (long)k * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = i * 64 + lane;
+      if (c4 < n4) {
+        const float4 a = ur[c4], w = wr[c4];
+        acc[i].x = fmaf(a.x, w.x, acc[i].x); acc[i].y = fmaf(a.y, w.y, acc[i].y);
+        acc[i].z = fmaf(a.z, w.z, acc[i].z); acc[i].w = fmaf(a.w, w.w, acc[i].w);
+      }
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) sum += (acc[i].x + acc[i].y) + (acc[i].z + acc[i].w);     // lanes past the row hold zeros
+  const float mu = wsum(sum) / (float)d;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (i * 64 + lane < n4) {
+      const float dx = acc[i].x - mu, dy = acc[i].y - mu, dz = acc[i].z - mu, dw = acc[i].w - mu;
+      sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  const float rstd = 1.0f / sqrtf(wsum(sq) / (float)d + eps);
+  float4* orow = reinterpret_cast<float4*>(out + row * d);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = i * 64 + lane;
+    if (c4 < n4) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
+      orow[c4] = make_float4(swishf((acc[i].x - mu) * rstd * g.x + b.x), swishf((acc[i].y - mu) * rstd * g.y + b.y),
+                             swishf((acc[i].z - mu) * rstd * g.z + b.z), swishf((acc[i].w - mu) * rstd * g.w + b.w));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Relative-position self-attention over time (RelPosMHAXL as published by speechbrain):
+//   score[i][j] = scale * ( (q_i + u_h) . k_j  +  (q_i + v_h) . P_h[(L-1) + j - i] ),
+//   ctx = softmax_j(score) V,   scale = 1/sqrt(embed_dim), P = linear_pos(sinusoid table).
+// qkv [BS][L][3d] in the standard layout (Q | K | V, head h at columns h*HD; the launcher's
+// caller permutes speechbrain's per-head (q,k,v) interleave when packing in_proj_weight),
+// P [2L-1][d], bu / bv [d] (flat, head-major as pos_bias_*.view(1,1,H,hd) reads them).
+// Per (sequence, head, 16-query tile) a flash-style sweep over 64-key tiles held in LDS with
+// an online softmax, exact fp32 VALU arithmetic; the P rows a tile needs are the 79
+// consecutive rows (L-1) + k0 - q0 - 15 .. + 78.  thread = (query q = tid/16, sub-lane
+// sl = tid%16): scores for keys sl + 16 jj, output dims sl + 16 i.
+// ---------------------------------------------------------------------------------------
+constexpr int RA_BQ = 16, RA_KT = 64, RA_PR = RA_KT + RA_BQ - 1;
+
+template <int HD>
+__global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                               const float* __restrict__ bu, const float* __restrict__ bv,
+                                                               int L, int d, float scale, float* __restrict__ ctx) {
+  constexpr int LDK = HD + 1, ND = HD / 16;
+  extern __shared__ __align__(16) float smem[];
+  float* Qu = smem;                       // [BQ][HD]   (q + u) * scale
+  float* Qv = Qu + RA_BQ * HD;            // [BQ][HD]   (q + v) * scale
+  float* Ks = Qv + RA_BQ * HD;            // [KT][HD+1]
+  float* Vs = Ks + RA_KT * LDK;           // [KT][HD]
+  float* Pw = Vs + RA_KT * HD;            // [PR][HD+1] window of P rows for this (query tile, key tile)
+  float* Pr = Pw + RA_PR * LDK;           // [BQ][KT] probabilities
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RA_BQ;
+  const int tid = threadIdx.x, q = tid >> 4, sl = tid & 15;
+  const float* base = qkv + (long)b * L * 3 * d;
+
+  for (int i = tid; i < RA_BQ * HD; i += 256) {
+    const int r = i / HD, c = i - r * HD;
+    const float qq = (q0 + r < L) ? base[(long)(q0 + r) * 3 * d + h * HD + c] : 0.f;
+    Qu[i] = (qq + bu[h * HD + c]) * scale;
+    Qv[i] = (qq + bv[h * HD + c]) * scale;
+  }
+  float acc[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) acc[i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int k0 = 0; k0 < L; k0 += RA_KT) {
+    const int kn = L - k0 < RA_KT ? L - k0 : RA_KT;
+    __syncthreads();                      // previous tile fully consumed (also covers Qu / Qv)
+    for (int i = tid; i < RA_KT * HD; i += 256) {
+      const int r = i / HD, c = i - r * HD;
+      float kv = 0.f, vv = 0.f;
+      if (r < kn) {
+        const float* row = base + (long)(k0 + r) * 3 * d + h * HD + c;
+        kv = row[d];
+        vv = row[2 * d];
+      }
+      Ks[r * LDK + c] = kv;
+      Vs[r * HD + c] = vv;
+    }
+    const int pbase = (L - 1) + k0 - q0 - (RA_BQ - 1);
+    for (int i = tid; i < RA_PR * HD; i += 256) {
+      const int r = i / HD, c = i - r * HD;
+      const int m = pbase + r;
+      Pw[r * LDK + c] = (m >= 0 && m <= 2 * L - 2) ? P[(long)m * d + h * HD + c] : 0.f;
+    }
+    __syncthreads();
+    float sc[RA_KT / 16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < RA_KT / 16; ++jj) {
+      const int j = sl + 16 * jj;
+      const float* kr = Ks + j * LDK;
+      const float* pr = Pw + (j - q + RA_BQ - 1) * LDK;
+      float s = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < HD; ++c) s = fmaf(Qu[q * HD + c], kr[c], fmaf(Qv[q * HD + c], pr[c], s));
+      sc[jj] = (j < kn) ? s : -INFINITY;
+      tmax = fmaxf(tmax, sc[jj]);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < RA_KT / 16; ++jj) {
+      const float pv = (sc[jj] == -INFINITY) ? 0.f : expf(sc[jj] - m_new);
+      Pr[q * RA_KT + sl + 16 * jj] = pv;
+      psum += pv;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ND; ++i) acc[i] *= alpha;
+    for (int j = 0; j < kn; ++j) {
+      const float pv = Pr[q * RA_KT + j];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) acc[i] = fmaf(pv, Vs[j * HD + sl + 16 * i], acc[i]);
+    }
+  }
+  if (q0 + q < L) {
+    const float inv = 1.0f / l_run;
+    float* o = ctx + ((long)b * L + q0 + q) * d + h * HD;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[sl + 16 * i] = acc[i] * inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Inter-speaker attention: at every (item n, time step t, head h) the S speakers are the
+// sequence (nn.MultiheadAttention inside nn.TransformerEncoderLayer(batch_first), applied to
+// x.reshape(N*T, S, F), SpeakerSeparation/network.py:311-316).  qkv [N][S][L][3d] standard
+// layout with in_proj bias already added; ctx [N][S][L][d].  One wave per (n, t): lanes are the
+// head dimension (hd <= 64); lane s2 keeps score (s1, s2); S <= 64.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void inter_attention_kernel(const float* __restrict__ qkv, int NB, int S, int L, int d,
+                                                              int nhead, float* __restrict__ ctx) {
+  const long nt = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (nt >= (long)NB * L) return;
+  const int n = (int)(nt / L), t = (int)(nt - (long)n * L);
+  const int hd = d / nhead;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const bool on = lane < hd;
+  for (int h = 0; h < nhead; ++h) {
+    for (int s1 = 0; s1 < S; ++s1) {
+      const long r1 = ((long)(n * S + s1) * L + t);
+      const float qv = on ? qkv[r1 * 3 * d + h * hd + lane] * scale : 0.f;
+      float mine = -INFINITY;                                   // lane s2 keeps score (s1, s2)
+      for (int s2 = 0; s2 < S; ++s2) {
+        const long r2 = ((long)(n * S + s2) * L + t);
+        const float kv = on ? qkv[r2 * 3 * d + d + h * hd + lane] : 0.f;
+        const float dot = wsum(qv * kv);
+        if (lane == s2) mine = dot;
+      }
+      const float mx = wmax(mine);
+      const float e = lane < S ? expf(mine - mx) : 0.f;
+      const float p = e / wsum(e);
+      float acc = 0.f;
+      for (int s2 = 0; s2 < S; ++s2) {
+        const long r2 = ((long)(n * S + s2) * L + t);
+        const float vv = on ? qkv[r2 * 3 * d + 2 * d + h * hd + lane] : 0.f;
+        acc = fmaf(__shfl(p, s2, 64), vv, acc);
+      }
+      if (on) ctx[r1 * d + h * hd + lane] = acc;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int asw_joint_shift_stats(const float* mix, int M, int T, const int32_t* offsets, int S, double* scratch,
+                                     float* mean, float* std, void* stream) {
+  ASW_CHECK_ARG(mix && offsets && scratch && mean && std, "joint_shift_stats: null pointer");
+  ASW_CHECK_ARG(M >= 1 && S >= 1 && S * M <= JS_MAXCH && T >= 2, "joint_shift_stats: S=%d M=%d T=%d unsupported (S*M <= %d)", S,
+                M, T, JS_MAXCH);
+  hipStream_t s = asw::as_stream(stream);
+  const int nb = asw::cdiv(T, 256) < JS_BLOCKS ? asw::cdiv(T, 256) : JS_BLOCKS;
+  hipLaunchKernelGGL(joint_stats_partial_kernel, dim3(nb), dim3(256), 0, s, mix, M, T, offsets, S, scratch);
+  ASW_LAUNCH_CHECK();
+  hipLaunchKernelGGL(joint_stats_final_kernel, dim3(1), dim3(64), 0, s, scratch, nb, T, S, mean, std);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+extern "C" int asw_joint_shift_stats_scratch_doubles(void) { return 2 * JS_BLOCKS; }
+
+extern "C" int asw_add_layernorm2(const float* x, const float* y, float alpha, const float* gamma, const float* beta,
+                                  int rows, int N, float eps, int act, float* sum_out, float* ln_out, void* stream) {
+  ASW_CHECK_ARG(x && (sum_out || ln_out), "add_layernorm2: null pointer");
+  ASW_CHECK_ARG(!ln_out || (gamma && beta), "add_layernorm2: LayerNorm needs gamma and beta");
+  ASW_CHECK_ARG(rows >= 0 && N > 0 && N % 4 == 0 && N <= 2048, "add_layernorm2: N=%d must be a multiple of 4, <= 2048", N);
+  ASW_CHECK_ARG(act == 0 || act == 2, "add_layernorm2: act must be 0 (none) or 2 (Swish)");
+  if (rows == 0) return ASW_OK;
+  hipStream_t s = asw::as_stream(stream);
+  dim3 grid(asw::cdiv(rows, 4));
+  switch ((N + 255) / 256) {
+#define ASW_ALN2(NV) case NV: hipLaunchKernelGGL(add_ln2_kernel<NV>, grid, dim3(256), 0, s, x, y, alpha, gamma, beta, rows, N, eps, act, sum_out, ln_out); break;
+    ASW_ALN2(1) ASW_ALN2(2) ASW_ALN2(3) ASW_ALN2(4) ASW_ALN2(5) ASW_ALN2(6) ASW_ALN2(7) ASW_ALN2(8)
+#undef ASW_ALN2
+  }
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+extern "C" int asw_glu_rows(const float* raw, long rows, int C, float* out, void* stream) {
+  ASW_CHECK_ARG(raw && out, "glu_rows: null pointer");
+  ASW_CHECK_ARG(rows >= 0 && C > 0 && C % 4 == 0, "glu_rows: C=%d must be a multiple of 4", C);
+  if (rows == 0) return ASW_OK;
+  const long total = rows * (C / 4);
+  const int blocks = (int)(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+  hipLaunchKernelGGL(glu_rows_kernel, dim3(blocks), dim3(256), 0, asw::as_stream(stream), raw, rows, C, out);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+extern "C" int asw_dwconv_ln_swish(const float* u, const float* wT, const float* bias, const float* gamma, const float* beta,
+                                   int BS, int L, int d, int K, float eps, float* out, void* stream) {
+  ASW_CHECK_ARG(u && wT && bias && gamma && beta && out, "dwconv_ln_swish: null pointer");
+  ASW_CHECK_ARG(BS > 0 && L > 0 && d > 0 && d % 4 == 0 && d <= 1024 && K >= 1 && K % 2 == 1,
+                "dwconv_ln_swish: bad shape (d %% 4, d <= 1024, odd K)");
+  hipStream_t s = asw::as_stream(stream);
+  dim3 grid(asw::cdiv((long)BS * L, 4));
+  switch ((d + 255) / 256) {
+#define ASW_DW(NV) case NV: hipLaunchKernelGGL(dwconv_ln_swish_kernel<NV>, grid, dim3(256), 0, s, u, wT, bias, gamma, beta, BS, L, d, K, eps, out); break;
+    ASW_DW(1) ASW_DW(2) ASW_DW(3) ASW_DW(4)
+#undef ASW_DW
+  }
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+namespace {
+template <int HD>
+int launch_relpos(const float* qkv, const float* P, const float* bu, const float* bv, int BS, int L, int d, int nhead,
+                  float scale, float* ctx, hipStream_t s) {
+  constexpr size_t smem = sizeof(float) * ((size_t)2 * RA_BQ * HD + (size_t)RA_KT * (HD + 1) + (size_t)RA_KT * HD +
+                                           (size_t)RA_PR * (HD + 1) + (size_t)RA_BQ * RA_KT);
+  static asw::SmemAttr attr;                                   // per device
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(relpos_attention_kernel<HD>), smem)) return rc;
+  dim3 grid(asw::cdiv(L, RA_BQ), nhead, BS);
+  asw::ProfScope prof(s, "relpos_attention", 6.0 * BS * nhead * (double)L * L * HD);
+  hipLaunchKernelGGL(relpos_attention_kernel<HD>, grid, dim3(256), smem, s, qkv, P, bu, bv, L, d, scale, ctx);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+}  // namespace
+
+extern "C" int asw_relpos_attention(const float* qkv, const float* P, const float* bias_u, const float* bias_v, int BS, int L,
+                                    int d, int nhead, float scale, float* ctx, void* stream) {
+  ASW_CHECK_ARG(qkv && P && bias_u && bias_v && ctx, "relpos_attention: null pointer");
+  ASW_CHECK_ARG(BS > 0 && BS <= 65535 && L > 0 && nhead > 0 && nhead <= 65535 && d % nhead == 0, "relpos_attention: bad shape");
+  hipStream_t s = asw::as_stream(stream);
+  switch (d / nhead) {
+    case 16: return launch_relpos<16>(qkv, P, bias_u, bias_v, BS, L, d, nhead, scale, ctx, s);
+    case 32: return launch_relpos<32>(qkv, P, bias_u, bias_v, BS, L, d, nhead, scale, ctx, s);
+    case 64: return launch_relpos<64>(qkv, P, bias_u, bias_v, BS, L, d, nhead, scale, ctx, s);
+    default: return asw::set_error(ASW_ERR_ARG, "relpos_attention: head_dim %d unsupported (16, 32, 64)", d / nhead);
+  }
+}
+
+extern "C" int asw_inter_attention(const float* qkv, int NB, int S, int L, int d, int nhead, float* ctx, void* stream) {
+  ASW_CHECK_ARG(qkv && ctx, "inter_attention: null pointer");
+  ASW_CHECK_ARG(NB > 0 && S > 0 && S <= 64 && L > 0 && nhead > 0 && d % nhead == 0 && d / nhead <= 64,
+                "inter_attention: bad shape (S <= 64, head_dim <= 64)");
+  dim3 grid(asw::cdiv((long)NB * L, 4));
+  hipLaunchKernelGGL(inter_attention_kernel, grid, dim3(256), 0, asw::as_stream(stream), qkv, NB, S, L, d, nhead, ctx);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}

@@ -14,81 +14,13 @@
 #include <string>
 #include <vector>
 
-#include "asw_common.h"
+#include "model_common.h"
+
+using namespace asw_model;
 
 namespace {
 
-struct DevBuf {
-  float* p = nullptr;
-  size_t n = 0;
-  DevBuf() = default;
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int upload(const std::vector<float>& h) {
-    if (p) { (void)hipFree(p); p = nullptr; }
-    n = h.size();
-    if (hipMalloc(&p, n * sizeof(float)) != hipSuccess) return asw::set_error(ASW_ERR_NOMEM, "hipMalloc(%zu floats)", n);
-    ASW_HIP(hipMemcpy(p, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    return ASW_OK;
-  }
-};
 
-// A GEMM weight in both arithmetic forms: fp32 (exact f32 MFMA) and the fp16 hi/lo split
-// with its power-of-two pre-scale (f16x3 MFMA), see convgemm.hip.
-struct WBuf {
-  DevBuf f32;
-  uint16_t* hi = nullptr;
-  uint16_t* lo = nullptr;
-  int32_t shift = 0;
-  WBuf() = default;
-  WBuf(const WBuf&) = delete;
-  WBuf& operator=(const WBuf&) = delete;
-  WBuf(WBuf&& o) noexcept : f32(std::move(o.f32)), hi(o.hi), lo(o.lo), shift(o.shift), fhi(o.fhi), flo(o.flo) {
-    o.hi = o.lo = o.fhi = o.flo = nullptr;
-  }
-  ~WBuf() {
-    if (hi) (void)hipFree(hi);
-    if (lo) (void)hipFree(lo);
-    if (fhi) (void)hipFree(fhi);
-    if (flo) (void)hipFree(flo);
-  }
-  int upload(const std::vector<float>& h) {
-    int rc = f32.upload(h);
-    if (rc) return rc;
-    std::vector<uint16_t> vh(h.size()), vl(h.size());
-    if ((rc = asw_split_weights_f16(h.data(), h.size(), vh.data(), vl.data(), &shift))) return rc;
-    if (hi) { (void)hipFree(hi); hi = nullptr; }
-    if (lo) { (void)hipFree(lo); lo = nullptr; }
-    if (hipMalloc(&hi, h.size() * 2) != hipSuccess || hipMalloc(&lo, h.size() * 2) != hipSuccess)
-      return asw::set_error(ASW_ERR_NOMEM, "hipMalloc(%zu halves)", h.size());
-    ASW_HIP(hipMemcpy(hi, vh.data(), h.size() * 2, hipMemcpyHostToDevice));
-    ASW_HIP(hipMemcpy(lo, vl.data(), h.size() * 2, hipMemcpyHostToDevice));
-    return ASW_OK;
-  }
-  // fragment-major copy for the halo-staged residual conv (Wt is [N][K])
-  uint16_t* fhi = nullptr;
-  uint16_t* flo = nullptr;
-  int upload_frags(const std::vector<float>& h, int N, int K) {
-    std::vector<uint16_t> vh(h.size()), vl(h.size());
-    int32_t sh = 0;
-    int rc = asw_pack_fragments_f16(h.data(), N, K, vh.data(), vl.data(), &sh);
-    if (rc) return rc;
-    if (sh != shift) return asw::set_error(ASW_ERR_STATE, "fragment pack: inconsistent weight shift");
-    if (hipMalloc(&fhi, h.size() * 2) != hipSuccess || hipMalloc(&flo, h.size() * 2) != hipSuccess)
-      return asw::set_error(ASW_ERR_NOMEM, "hipMalloc(%zu halves)", h.size());
-    ASW_HIP(hipMemcpy(fhi, vh.data(), h.size() * 2, hipMemcpyHostToDevice));
-    ASW_HIP(hipMemcpy(flo, vl.data(), h.size() * 2, hipMemcpyHostToDevice));
-    return ASW_OK;
-  }
-  void bind(asw_convgemm_args& a, int precision) const {
-    a.Wt = f32.p; a.Wt_hi = hi; a.Wt_lo = lo; a.w_shift = shift; a.precision = precision;
-    a.Wf_hi = fhi; a.Wf_lo = flo;
-  }
-};
-
-struct ResLayer { WBuf wt; DevBuf bias, g, b; int dil = 1; };
 struct EncBlock { std::vector<ResLayer> res; DevBuf bias, gn_g, gn_b; int cin = 0, cout = 0, stride = 1; };
 struct DecBlock { std::vector<ResLayer> res; DevBuf gn_g, gn_b; int cin = 0, cout = 0, stride = 1; };
 struct TfLayer { WBuf w_in, w_out, w1, w2; DevBuf b_in, b_out, b1, b2, n1g, n1b, n2g, n2b; };
@@ -202,37 +134,9 @@ std::vector<std::pair<std::string, size_t>> expected_params(const asw_spot* m) {
   return v;
 }
 
-// conv weight [N][Cin][K] -> Wt[N][tap*Cin + c] (optionally scaled per input channel)
-std::vector<float> pack_conv(const std::vector<float>& w, int N, int Cin, int K, const float* in_gate) {
-  std::vector<float> o((size_t)N * Cin * K);
-  for (int n = 0; n < N; ++n)
-    for (int c = 0; c < Cin; ++c)
-      for (int k = 0; k < K; ++k)
-        o[((size_t)n * K + k) * Cin + c] = w[((size_t)n * Cin + c) * K + k] * (in_gate ? in_gate[c] : 1.f);
-  return o;
-}
-
 int pack_res(asw_spot* m, const std::string& p, int ch, std::vector<ResLayer>& out) {
   const asw_spot_config& c = m->cfg;
-  out.resize(c.residual_layers);
-  int dil = 1;
-  for (int j = 0; j < c.residual_layers; ++j) {
-    const std::string q = p + ".res.seq." + std::to_string(j);
-    int rc;
-    {
-      const std::vector<float> packed = pack_conv(P(m, q + ".conv.weight"), ch, ch, c.kernel_size, nullptr);
-      if ((rc = out[j].wt.upload(packed))) return rc;
-      if (ch % 32 == 0 && (ch * c.kernel_size) % 16 == 0 &&
-          (rc = out[j].wt.upload_frags(packed, ch, ch * c.kernel_size)))
-        return rc;
-    }
-    if ((rc = out[j].bias.upload(P(m, q + ".conv.bias")))) return rc;
-    if ((rc = out[j].g.upload(P(m, q + ".norm.weight")))) return rc;
-    if ((rc = out[j].b.upload(P(m, q + ".norm.bias")))) return rc;
-    out[j].dil = dil;
-    dil *= c.residual_dilation_factor;
-  }
-  return ASW_OK;
+  return pack_res_layers(m->raw, p, ch, c.kernel_size, c.residual_layers, c.residual_dilation_factor, out);
 }
 
 // gate[c] = W[c][0]*w0 + W[c][1]*w1 + b[c]   (embed1 is Conv1d(2->C, k=1))
@@ -290,21 +194,6 @@ int get_gates(asw_spot* m, float w0, float w1, GateSet** out) {
   m->gates[key] = std::move(gs);
   return ASW_OK;
 }
-
-// ---- workspace arena --------------------------------------------------------
-struct Arena {
-  char* base;
-  size_t off = 0, cap;
-  bool dry;
-  Arena(char* b, size_t c, bool d) : base(b), cap(c), dry(d) {}
-  template <typename T>
-  T* take(size_t n) {
-    off = (off + 255) & ~(size_t)255;
-    T* p = reinterpret_cast<T*>(base + off);
-    off += n * sizeof(T);
-    return p;
-  }
-};
 
 struct Plan {
   int B, T, Tp, F, RL, depth;
@@ -373,47 +262,6 @@ int ensure_ws(asw_spot* m, int B, int T, Plan& pl) {
   Arena real(m->ws, m->ws_bytes, false);
   layout(m, B, T, real, pl);
   return ASW_OK;
-}
-
-int run_res(const std::vector<ResLayer>& res, int prec, int B, int T, int ch, int K, float* x, float* p, float* q,
-            float** final_out, hipStream_t s) {
-  // ping-pong: layer 0 reads x (kept intact), later layers alternate p/q
-  const float* in = x;
-  float* outb = p;
-  for (size_t j = 0; j < res.size(); ++j) {
-    asw_convgemm_args a = {};
-    a.A = in; res[j].wt.bind(a, prec); a.bias = res[j].bias.p; a.resid = in;
-    a.ln_gamma = res[j].g.p; a.ln_beta = res[j].b.p; a.out = outb;
-    a.B = B; a.M_out = T; a.N = ch; a.Cin = ch; a.taps = K; a.stride = 1; a.dil = res[j].dil;
-    a.pad = (res[j].dil * (K - 1) + 1) / 2;
-    a.a_row_stride = ch; a.a_batch_stride = (int64_t)T * ch; a.a_len = (int64_t)T * ch;
-    a.relu = 1; a.ln_eps = 1e-5f;
-    int rc = asw_convgemm_f32(&a, s);
-    if (rc) return rc;
-    in = outb;
-    outb = (outb == p) ? q : p;
-  }
-  *final_out = const_cast<float*>(in);
-  return ASW_OK;
-}
-
-int linear(const float* A, const WBuf& W, int prec, const float* bias, int rows, int N, int K, int relu, const float* resid,
-           const float* g, const float* b, float* out, hipStream_t s) {
-  asw_convgemm_args a = {};
-  a.A = A; W.bind(a, prec); a.bias = bias; a.resid = resid; a.ln_gamma = g; a.ln_beta = b; a.out = out;
-  a.B = 1; a.M_out = rows; a.N = N; a.Cin = K; a.taps = 1; a.stride = 1; a.dil = 1; a.pad = 0;
-  a.a_row_stride = K; a.a_batch_stride = (int64_t)rows * K; a.a_len = (int64_t)rows * K;
-  a.relu = relu; a.ln_eps = 1e-5f;
-  if (g && N >= 1024 && N % 256 == 0 && N <= 2048) {
-    // a LayerNorm-fused tile must hold the whole row: at d = 1024 that leaves 32 rows per
-    // workgroup and every workgroup re-reads all of W (measured 75 TFLOP/s).  Run the GEMM on
-    // the wide tile instead and normalise in one extra pass over the rows (240 TFLOP/s + 30 us).
-    a.resid = nullptr; a.ln_gamma = nullptr; a.ln_beta = nullptr;
-    int rc = asw_convgemm_f32(&a, s);
-    if (rc) return rc;
-    return asw_add_layernorm(out, resid, g, b, rows, N, 1e-5f, out, s);
-  }
-  return asw_convgemm_f32(&a, s);
 }
 
 // everything after the preproc stage; pl.X[0] / pl.refn are filled
