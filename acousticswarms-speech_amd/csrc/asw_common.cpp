@@ -24,7 +24,7 @@ int SmemAttr::ensure(const void* kern, size_t want) {
 }  // namespace asw
 
 extern "C" const char* asw_last_error(void) { return asw::err_buf(); }
-extern "C" int asw_abi_version(void) { return 1; }
+extern "C" int asw_abi_version(void) { return 2; }   // 2: + joint separation network (asw_sep_*)
 
 // ---- launch profiler -----------------------------------------------------------------
 #include <map>

@@ -79,7 +79,8 @@ floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
       for (int r = 0; r < 16; ++r) {
         const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         float v = acc[tm][tn][r] * acc_scale + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu == 1) v = fmaxf(v, 0.f);
+        else if (p.relu == 2) v = v / (1.0f + expf(-v));             // Swish (Conformer feed-forward)
         Ct[row * LDC + col] = v;
       }
     }

@@ -5,9 +5,10 @@
 
 Unlike the reference's timers (host ``time.time()`` with no device synchronisation,
 :143-148) each stage boundary here synchronises the device, so the numbers are true
-stage latencies.  The joint separation network (``sep_model``; speechbrain Conformer
-bottleneck) is a SURVEY.md §8f "next" row: any object with ``infer(mix, patches)`` can be
-plugged in; with ``sep_model=None`` stage 4 is skipped and ``audio`` is None.
+stage latencies.  ``sep_model`` is the joint separation network (``sep.SepModel``, the HIP
+implementation of sep/training/SpeakerSeparation/network.py) or any object with
+``infer(mix, patches)``; with ``sep_model=None`` the separation stage is skipped, ``audio`` is
+None and ``times[4]`` stays 0 (callers must then report a localize-only latency).
 """
 import time
 

@@ -14,23 +14,60 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASW_LIB_PATH") or os.path.join(_HERE, "libasw_hip.so")   # env: A/B builds only
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["asw_common.cpp", "convgemm.hip", "prep_kernels.hip", "misc_kernels.hip", "attention_mfma.hip", "srp_kernels.hip", "search_host.cpp",
-           "spot_model.hip"]
+SOURCES = ["asw_common.cpp", "convgemm.hip", "prep_kernels.hip", "misc_kernels.hip", "attention_mfma.hip", "srp_kernels.hip",
+           "search_host.cpp", "sep_kernels.hip", "spot_model.hip", "sep_model.hip"]
+HEADERS = ["asw_common.h", "model_common.h"]
+OPS_PATH = os.path.join(_HERE, "libasw_torch_ops.so")      # TORCH_LIBRARY(asw, ...) adapters over the C ABI
+OPS_SOURCE = "torch_ops.cpp"
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into libasw_hip.so (in-tree)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "asw_common.h"),
-                   os.path.join(os.path.dirname(_HERE), "include", "asw_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    """Compile every HIP source for gfx950 into libasw_hip.so (in-tree): one object per source
+    under build/ (only the stale ones, in parallel), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(os.path.dirname(_HERE), "include", "asw_hip.h")]
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_time):
+            jobs.append(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-c", sp, "-o", op])
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs)
+    return LIB_PATH
+
+
+def build_torch_ops(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/torch_ops.cpp (host code only: TORCH_LIBRARY registration + argument checks)
+    against this interpreter's torch headers and link it to libasw_hip.so, in-tree."""
+    import torch
+    src = os.path.join(CSRC, OPS_SOURCE)
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "asw_hip.h")
+    if not force and os.path.exists(OPS_PATH) and os.path.getmtime(OPS_PATH) >= max(
+            os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB_PATH)):
+        return OPS_PATH
+    ti = os.path.dirname(torch.__file__)
+    cmd = ["hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w",
+           f"-I{ti}/include", f"-I{ti}/include/torch/csrc/api/include", "-I/opt/rocm/include", src, "-o", OPS_PATH,
+           f"-L{_HERE}", "-lasw_hip", f"-L{ti}/lib", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{ti}/lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return OPS_PATH
 
 
 class SpotConfigC(Structure):
@@ -52,6 +89,27 @@ class SpotConfigC(Structure):
         s.encoder_stride, s.residual_layers = cfg.encoder_stride, cfg.residual_layers
         s.residual_dilation_factor, s.num_head = cfg.residual_dilation_factor, cfg.num_head
         s.ffw_dim, s.num_transformer_layers = cfg.ffw_dim, cfg.num_transformer_layers
+        return s
+
+
+class SepConfigC(Structure):
+    _fields_ = [("n_mics", c_int32), ("max_speakers", c_int32), ("kernel_size", c_int32), ("depth", c_int32),
+                ("stride_list", c_int32 * 8), ("channels", c_int32), ("growth", c_int32),
+                ("encoder_channels", c_int32), ("encoder_kernel_size", c_int32), ("encoder_stride", c_int32),
+                ("residual_layers", c_int32), ("residual_dilation_factor", c_int32), ("num_head", c_int32),
+                ("ffw_dim", c_int32), ("bottleneck_layers", c_int32), ("bottleneck_ksize", c_int32)]
+
+    @classmethod
+    def from_config(cls, cfg):
+        s = cls()
+        s.n_mics, s.max_speakers, s.kernel_size, s.depth = cfg.n_mics, cfg.max_speakers, cfg.kernel_size, cfg.depth
+        for i, v in enumerate(cfg.stride_list):
+            s.stride_list[i] = v
+        s.channels, s.growth = cfg.channels, int(cfg.growth)
+        s.encoder_channels, s.encoder_kernel_size = cfg.encoder_channels, cfg.encoder_kernel_size
+        s.encoder_stride, s.residual_layers = cfg.encoder_stride, cfg.residual_layers
+        s.residual_dilation_factor, s.num_head = cfg.residual_dilation_factor, cfg.num_head
+        s.ffw_dim, s.bottleneck_layers, s.bottleneck_ksize = cfg.ffw_dim, cfg.bottleneck_layers, cfg.bottleneck_ksize
         return s
 
 
@@ -84,6 +142,24 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_int, c_void_p]),
     "asw_spot_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p, c_void_p]),
     "asw_spot_get_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]),
+    "asw_sep_create": (c_int, [POINTER(SepConfigC), POINTER(c_void_p)]),
+    "asw_sep_destroy": (None, [c_void_p]),
+    "asw_sep_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    "asw_sep_finalize": (c_int, [c_void_p]),
+    "asw_sep_set_precision": (c_int, [c_void_p, c_int]),
+    "asw_sep_infer": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "asw_sep_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "asw_sep_get_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]),
+    "asw_joint_shift_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "asw_joint_shift_stats_scratch_doubles": (c_int, []),
+    "asw_add_layernorm2": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
+                                   c_void_p, c_void_p, c_void_p]),
+    "asw_glu_rows": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "asw_dwconv_ln_swish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_float, c_void_p, c_void_p]),
+    "asw_relpos_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                     c_void_p, c_void_p]),
+    "asw_inter_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "asw_shift_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asw_shift_norm_preproc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p]),
@@ -135,6 +211,24 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+_ops = None
+
+
+def torch_ops():
+    """``torch.ops.asw`` -- the PyTorch-ROCm custom ops the host classes call (csrc/torch_ops.cpp).
+    Loads libasw_hip.so first, then the adapter library; raises when either has not been built."""
+    global _ops
+    if _ops is None:
+        lib()
+        if not os.path.exists(OPS_PATH):
+            raise RuntimeError(f"{OPS_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`.  "
+                               "The hot path is exposed only through these custom ops; there is no fallback.")
+        import torch
+        torch.ops.load_library(OPS_PATH)
+        _ops = torch.ops.asw
+    return _ops
 
 
 def check(status: int):

@@ -164,3 +164,60 @@ def pair_sisdr(y):
     out = torch.empty((n, n), dtype=torch.float64, device=y.device)
     check(lib().asw_pair_sisdr(ptr(_f32(y)), n, T, ptr(out), current_stream()))
     return out
+
+
+# ---- kernels of the joint separation network (csrc/sep_kernels.hip) --------------------------
+def joint_shift_stats(mix, offsets):
+    """mean / unbiased std of the all-channel average of the S*M zero-fill shifted channels."""
+    M, T = mix.shape
+    S = offsets.shape[0]
+    scratch = torch.empty((lib().asw_joint_shift_stats_scratch_doubles(),), dtype=torch.float64, device=mix.device)
+    mean = torch.empty((S,), dtype=torch.float32, device=mix.device)
+    std = torch.empty((S,), dtype=torch.float32, device=mix.device)
+    check(lib().asw_joint_shift_stats(ptr(_f32(mix)), M, T, ptr(offsets), S, ptr(scratch), ptr(mean), ptr(std),
+                                      current_stream()))
+    return mean, std
+
+
+def add_layernorm2(x, y=None, alpha=1.0, gamma=None, beta=None, eps=1e-5, act=0, want_sum=False, want_ln=True):
+    rows, N = x.shape
+    s = torch.empty_like(x) if want_sum else None
+    o = torch.empty_like(x) if want_ln else None
+    check(lib().asw_add_layernorm2(ptr(_f32(x)), ptr(y), float(alpha), ptr(gamma), ptr(beta), rows, N, eps, act, ptr(s),
+                                   ptr(o), current_stream()))
+    return s, o
+
+
+def glu_rows(raw):
+    rows, C2 = raw.shape
+    out = torch.empty((rows, C2 // 2), dtype=torch.float32, device=raw.device)
+    check(lib().asw_glu_rows(ptr(_f32(raw)), rows, C2 // 2, ptr(out), current_stream()))
+    return out
+
+
+def dwconv_ln_swish(u, w, bias, gamma, beta, eps=1e-5):
+    """u [BS, L, d]; w torch depthwise weight [d, 1, K]."""
+    BS, L, d = u.shape
+    K = w.shape[-1]
+    wT = w.reshape(d, K).t().contiguous()
+    out = torch.empty_like(u)
+    check(lib().asw_dwconv_ln_swish(ptr(_f32(u)), ptr(_f32(wT)), ptr(_f32(bias)), ptr(_f32(gamma)), ptr(_f32(beta)),
+                                    BS, L, d, K, eps, ptr(out), current_stream()))
+    return out
+
+
+def relpos_attention(qkv, P, bias_u, bias_v, nhead, scale):
+    BS, L, d3 = qkv.shape
+    d = d3 // 3
+    ctx = torch.empty((BS, L, d), dtype=torch.float32, device=qkv.device)
+    check(lib().asw_relpos_attention(ptr(_f32(qkv)), ptr(_f32(P)), ptr(_f32(bias_u)), ptr(_f32(bias_v)), BS, L, d, nhead,
+                                     float(scale), ptr(ctx), current_stream()))
+    return ctx
+
+
+def inter_attention(qkv, nhead):
+    NB, S, L, d3 = qkv.shape
+    d = d3 // 3
+    ctx = torch.empty((NB, S, L, d), dtype=torch.float32, device=qkv.device)
+    check(lib().asw_inter_attention(ptr(_f32(qkv)), NB, S, L, d, nhead, ptr(ctx), current_stream()))
+    return ctx

@@ -3,12 +3,13 @@
 ``SpotModel`` keeps the names, argument meaning and return types of
 ``DataParallelSpotModel.shift_and_sep`` (sep/training/JointModel/network.py:27-104) and
 ``Network.forward`` (sep/training/SpeakerLocalization/network.py:363-405); all
-arithmetic runs in the HIP library.  PyTorch is used only for device memory and
-streams.  ``shift_and_score`` is the additive energies-only fast path:
+arithmetic runs in the HIP library, reached through the PyTorch-ROCm custom ops
+``torch.ops.asw.*`` (csrc/torch_ops.cpp, thin adapters over the C ABI).  PyTorch is used only
+for device memory and streams.  ``shift_and_score`` is the additive energies-only fast path:
 waveforms stay on the GPU, two doubles per candidate come back.
 """
 from collections import OrderedDict
-from ctypes import byref, c_float, c_size_t, c_void_p
+from ctypes import byref, c_size_t, c_void_p
 
 import numpy as np
 
@@ -139,14 +140,10 @@ class SpotModel:
         N = offsets_dev.shape[0]
         assert mix_dev.dtype == torch.float32 and mix_dev.is_contiguous() and mix_dev.is_cuda
         assert offsets_dev.dtype == torch.int32 and offsets_dev.is_contiguous() and offsets_dev.is_cuda
-        wave = torch.empty((N, T), dtype=torch.float32, device=mix_dev.device) if want_wave else None
-        en = torch.empty((N, 2), dtype=torch.float64, device=mix_dev.device) if want_energy else None
-        if N > 0:
-            with torch.cuda.device(mix_dev.device):
-                native.check(native.lib().asw_spot_shift_and_sep(
-                    self._h, native.ptr(mix_dev), M, T, native.ptr(offsets_dev), N, int(strict), int(circular),
-                    native.ptr(wave), native.ptr(en), int(window), native.current_stream()))
-        return wave, en
+        # torch.ops.asw.spot_shift_and_sep: runs on the tensors' device and torch's current stream
+        wave, en = native.torch_ops().spot_shift_and_sep(self._h.value, mix_dev, offsets_dev, int(strict), bool(circular),
+                                                         bool(want_wave), bool(want_energy), int(window))
+        return (wave if want_wave else None), (en if want_energy else None)
 
     # ---- reference call surface ---------------------------------------------------
     def shift_and_sep(self, input_channels, patch_list, Strict: int = 0, save_input: bool = False) -> np.ndarray:
@@ -202,23 +199,13 @@ class SpotModel:
         else:
             off_d = torch.from_numpy(offs).to(self.device)
         wave, en = self.shift_and_sep_device(mix_d, off_d, Strict, want_wave=True, want_energy=True, window=window)
-        if wave.shape[0] > 0:
-            with torch.cuda.device(self.device):
-                native.check(native.lib().asw_center_rows(native.ptr(wave), wave.shape[0], wave.shape[1],
-                                                          native.current_stream()))
+        native.torch_ops().center_rows_(wave)
         return wave, (en if device_energies else en.cpu().numpy())
 
     def pair_sisdr(self, waves):
         """SI-SDR matrix S[i][j] = si_sdr(est=waves[i], ref=waves[j]) computed on the GPU
         (sep/helpers/eval_utils.py:11-39); returns a host ndarray [n,n] float64."""
-        import torch
-        n, T = waves.shape
-        out = torch.empty((n, n), dtype=torch.float64, device=waves.device)
-        if n > 0:
-            with torch.cuda.device(waves.device):
-                native.check(native.lib().asw_pair_sisdr(native.ptr(waves.contiguous()), n, T, native.ptr(out),
-                                                         native.current_stream()))
-        return out.cpu().numpy()
+        return native.torch_ops().pair_sisdr(waves.contiguous()).cpu().numpy()
 
     def segment_sisdr(self, waves, segments):
         """Segment-wise SI-SDR tensor S[i][j][k] = si_sdr(waves[i][seg_k(i)], waves[j][seg_k(i)])
@@ -235,14 +222,8 @@ class SpotModel:
                 if not (0 <= a <= b <= T):
                     raise RuntimeError(f"segment [{a},{b}) of waveform {i} lies outside [0,{T}]")
                 seg[i, k] = (a, b)
-        out = torch.full((n, n, kmax), float("nan"), dtype=torch.float64, device=waves.device)
-        if n > 0:
-            with torch.cuda.device(waves.device):
-                seg_d = torch.from_numpy(seg).to(waves.device)
-                cnt_d = torch.from_numpy(cnt).to(waves.device)
-                native.check(native.lib().asw_segment_sisdr(native.ptr(waves.contiguous()), n, T, native.ptr(seg_d),
-                                                            native.ptr(cnt_d), kmax, native.ptr(out),
-                                                            native.current_stream()))
+        out = native.torch_ops().segment_sisdr(waves.contiguous(), torch.from_numpy(seg).to(waves.device),
+                                               torch.from_numpy(cnt).to(waves.device))
         return out.cpu().numpy(), cnt
 
     def forward(self, mix, window_embedding):
@@ -255,20 +236,16 @@ class SpotModel:
         wemb = torch.as_tensor(window_embedding, dtype=torch.float32).cpu().numpy().reshape(mix.shape[0], 2)
         B, M, t = mix.shape
         out = torch.empty((B, 1, t), dtype=torch.float32, device=self.device)
-        L = native.lib()
         keys = {}
         for i, row in enumerate(map(tuple, wemb)):
             keys.setdefault(row, []).append(i)
-        with torch.cuda.device(self.device):
-            for row, idx in keys.items():
-                whole = len(idx) == B
-                x = mix if whole else mix[idx].contiguous()
-                y = out.view(B, t) if whole else torch.empty((len(idx), t), dtype=torch.float32, device=self.device)
-                w = (c_float * 2)(float(row[0]), float(row[1]))
-                native.check(L.asw_spot_forward(self._h, native.ptr(x), len(idx), M, t, w, native.ptr(y),
-                                                native.current_stream()))
-                if not whole:
-                    out.view(B, t)[idx] = y
+        ops = native.torch_ops()
+        for row, idx in keys.items():
+            whole = len(idx) == B
+            y = ops.spot_forward(self._h.value, mix if whole else mix[idx].contiguous(), float(row[0]), float(row[1]))
+            if whole:
+                return y.view(B, 1, t)
+            out.view(B, t)[idx] = y
         return out
 
     __call__ = forward

@@ -214,31 +214,16 @@ class SRPPhat(object):
                 break
             n_win += 1
         t = self._device_tables(dev)
-        L = native.lib()
         sig = torch.as_tensor(signal, dtype=torch.float32).to(dev)
         Tp = (T + 3) // 4 * 4
         if Tp != T:
             sig = torch.nn.functional.pad(sig, (0, Tp - T))
         sig = sig.contiguous()
-        nb, P, G = len(self.freq_bins), len(self.pair_i), self.grids.shape[0]
         hop = self.n_fft // 4
-        F = L.asw_srp_frames(window, self.n_fft, hop)
-        xf = torch.empty((M, F, 2 * t["nb_pad"]), dtype=torch.float32, device=dev)
-        cc = torch.empty((max(n_win, 1), nb, P, 2), dtype=torch.float32, device=dev)
-        out = torch.zeros((G,), dtype=torch.float32, device=dev)
-        if n_win > 0:
-            with torch.cuda.device(dev):
-                st = native.current_stream()
-                native.check(L.asw_srp_cross_spectra(native.ptr(sig), M, Tp, window, step, n_win, self.n_fft, hop,
-                                                     nb, t["nb_pad"], float(tol), native.ptr(t["tw"]),
-                                                     native.ptr(t["pi"]), native.ptr(t["pj"]), P, native.ptr(xf),
-                                                     native.ptr(cc), st))
-                part = torch.empty((8 * 8 * G,), dtype=torch.float32, device=dev)
-                native.check(L.asw_srp_map(native.ptr(cc), n_win, nb, P, native.ptr(t["tau"]), G, M,
-                                           native.ptr(t["omega"]), native.ptr(t["pi"]), native.ptr(t["pj"]),
-                                           native.ptr(part), native.ptr(out), st))
+        # torch.ops.asw.srp_phat_map: DFT-GEMM + PHAT + cross-spectra, then the steered map
+        out = native.torch_ops().srp_phat_map(sig, t["tw"], t["pi"], t["pj"], t["tau"], t["omega"], int(window), int(step),
+                                              int(n_win), int(self.n_fft), int(hop), float(tol))
         self.SRP_map = out.cpu().numpy()
-        self._cc_last = cc
         self._finish_map()
 
     def set_map(self, srp_map):

@@ -114,6 +114,95 @@ int asw_spot_get_tap(asw_spot* m, const char* name, float* dst, size_t capacity,
                      void* stream);
 
 /* ------------------------------------------------------------------------
+ * Joint separation network ("separation by localization").  Mirrors Network.__init__
+ * (sep/training/SpeakerSeparation/network.py:323-416; experiments/separation/
+ * description.json:4-10).  The bottleneck's Conformer follows the published speechbrain
+ * definitions (the library is absent from the build image: parity of that part is pinned to
+ * this repository's restatement only, see oracle/sep_ref.py).
+ * ---------------------------------------------------------------------- */
+typedef struct asw_sep_config {
+  int32_t n_mics;                 /* 7 */
+  int32_t max_speakers;           /* 5 (constructor default 6): forward() pads its rows to this */
+  int32_t kernel_size;            /* 5 */
+  int32_t depth;                  /* len(stride_list) <= 8 */
+  int32_t stride_list[8];         /* 2,2,4,4 */
+  int32_t channels;               /* 64 */
+  int32_t growth;                 /* 2 */
+  int32_t encoder_channels;       /* 4096 */
+  int32_t encoder_kernel_size;    /* 33 */
+  int32_t encoder_stride;         /* 16 */
+  int32_t residual_layers;        /* 3 */
+  int32_t residual_dilation_factor; /* 2 */
+  int32_t num_head;               /* 8 */
+  int32_t ffw_dim;                /* 1024 */
+  int32_t bottleneck_layers;      /* 3 */
+  int32_t bottleneck_ksize;       /* 31 */
+} asw_sep_config;
+
+typedef struct asw_sep asw_sep;     /* opaque: device-resident weights + workspace */
+
+/* Network(**model_params).to(device) + load_state_dict(strict=True)
+ * (sep/helpers/utils.py:176-198); same protocol as the asw_spot_* calls above. */
+int asw_sep_create(const asw_sep_config* cfg, asw_sep** out);
+void asw_sep_destroy(asw_sep* m);
+int asw_sep_set_param(asw_sep* m, const char* key, const float* host_data, size_t numel);
+int asw_sep_finalize(asw_sep* m);
+int asw_sep_set_precision(asw_sep* m, int precision);
+
+/* Network.infer_sample (SpeakerSeparation/network.py:496-548): for each of the S speakers
+ * advance channel m>=1 of `mix` by offsets[s][m-1] samples with ZERO fill (:510-522), stack to
+ * S*M channels, int16-quantise and normalise with ONE mean / std over all of them (:534),
+ * run the network and un-normalise.
+ *   mix [M][T] float32 device; offsets [S][M-1] int32 device (already rounded, :507);
+ *   out [S][T] float32 device.  S <= 64. */
+int asw_sep_infer(asw_sep* m, const float* mix, int M, int T, const int32_t* offsets, int S, float* out,
+                  void* stream);
+
+/* Network.forward (:418-490) on already normalised input, every item with the same number of
+ * speakers: mix_norm [B][S*M][t] -> out [B][max(S, max_speakers)][t] (rows beyond S are zeros,
+ * :486-488).  B*S <= 64. */
+int asw_sep_forward(asw_sep* m, const float* mix_norm, int B, int S, int M, int t, float* out, void* stream);
+
+/* Debug/parity tap of the LAST call (channels-last [B*S][T_l][C] float32): "enc0".., "intra0"..,
+ * "inter0".., "bottleneck", "dec0".. */
+int asw_sep_get_tap(asw_sep* m, const char* name, float* dst, size_t capacity, size_t* numel, void* stream);
+
+/* Joint normalisation statistics of the S*M zero-fill-shifted, int16-quantised channels
+ * (SpeakerSeparation/network.py:510-534 with :28-35): mean / unbiased std over time of the
+ * all-channel average.  scratch: asw_joint_shift_stats_scratch_doubles() doubles (device).
+ * mean, std: [S] float32 (the same value S times, the layout the preproc kernel takes). */
+int asw_joint_shift_stats(const float* mix, int M, int T, const int32_t* offsets, int S, double* scratch,
+                          float* mean, float* std, void* stream);
+int asw_joint_shift_stats_scratch_doubles(void);
+
+/* Row kernel of the Conformer layer: s = x + alpha*y (y may be NULL); sum_out = s (may be NULL);
+ * ln_out = act(LayerNorm(s)*gamma + beta) (may be NULL; act 0 none, 2 Swish).  rows x N floats,
+ * N % 4 == 0, N <= 2048.  Replaces the residual adds and LayerNorms of ConformerEncoderLayer. */
+int asw_add_layernorm2(const float* x, const float* y, float alpha, const float* gamma, const float* beta,
+                       int rows, int N, float eps, int act, float* sum_out, float* ln_out, void* stream);
+
+/* nn.GLU over channels-last rows: raw [rows][2C] -> out [rows][C] = raw[:, :C] * sigmoid(raw[:, C:]). */
+int asw_glu_rows(const float* raw, long rows, int C, float* out, void* stream);
+
+/* ConvolutionModule tail: depthwise Conv1d(d, d, K, padding (K-1)/2, groups d) over time within
+ * each of the BS sequences + bias, LayerNorm over channels, Swish.  u, out [BS][L][d];
+ * wT [K][d] (tap-major copy of the [d][1][K] weight). */
+int asw_dwconv_ln_swish(const float* u, const float* wT, const float* bias, const float* gamma, const float* beta,
+                        int BS, int L, int d, int K, float eps, float* out, void* stream);
+
+/* Relative-position multi-head self-attention core (speechbrain RelPosMHAXL as published):
+ * score[i][j] = scale*((q_i+u).k_j + (q_i+v).P[(L-1)+j-i]); ctx = softmax(score) V.
+ * qkv [BS][L][3d] in Q|K|V layout (head h at columns h*hd), P [2L-1][d] = linear_pos(table),
+ * bias_u / bias_v [d] head-major; ctx [BS][L][d].  head_dim in {16, 32, 64}. */
+int asw_relpos_attention(const float* qkv, const float* P, const float* bias_u, const float* bias_v, int BS, int L,
+                         int d, int nhead, float scale, float* ctx, void* stream);
+
+/* Inter-speaker attention core: for every (item, time step, head) softmax(QK^T/sqrt(hd))V over the
+ * S speakers (nn.TransformerEncoderLayer on x.reshape(N*T, S, F), :311-316).
+ * qkv [NB][S][L][3d] (in_proj bias included) -> ctx [NB][S][L][d].  S <= 64, head_dim <= 64. */
+int asw_inter_attention(const float* qkv, int NB, int S, int L, int d, int nhead, float* ctx, void* stream);
+
+/* ------------------------------------------------------------------------
  * Individual kernels (unit-testable; the model above is built from these).
  * ---------------------------------------------------------------------- */
 
@@ -140,7 +229,7 @@ int asw_pad_preproc(const float* x, int B, int M, int t, int T_pad, const float*
  * f32 MFMA pipe with a fused epilogue.  Activations are channels-last.
  *   out[b][r][n] = epi( sum_{tap,c} A[b][(r*stride + tap*dil - pad)*a_row_stride + c]
  *                                    * Wt[n][tap*Cin + c] )
- * epi: +bias[n]; ReLU (relu!=0); +resid; *mul; LayerNorm over n (ln_gamma!=NULL,
+ * epi: +bias[n]; activation (relu: 0 none, 1 ReLU, 2 Swish x*sigmoid(x)); +resid; *mul; LayerNorm over n (ln_gamma!=NULL,
  * requires N in {64,128,256,512,1024}); group statistics partials (stats!=NULL).
  * Replaces nn.Conv1d / nn.ConvTranspose1d / nn.Linear + ReLU / residual / LayerNorm of
  * network.py:57-68,105-113,190-198 and the transformer linears. */

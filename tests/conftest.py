@@ -31,3 +31,5 @@ def _built_library():
     from acousticswarms_speech_amd import native
     if not os.path.exists(native.LIB_PATH):
         native.build()
+    if not os.path.exists(native.OPS_PATH):
+        native.build_torch_ops()

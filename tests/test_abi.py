@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in asw_hip.h but not exported"
     assert syms == set(native.SIGNATURES), (syms ^ set(native.SIGNATURES))
-    assert L.asw_abi_version() == 1
+    assert L.asw_abi_version() == 2
 
 
 def test_argument_errors_do_not_need_a_gpu():
@@ -79,3 +79,33 @@ def test_header_is_plain_c():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror",
                     os.path.join(root, "include", "asw_hip.h")], check=True)
+
+
+def test_torch_custom_ops_are_registered_without_a_gpu():
+    """TORCH_LIBRARY(asw, ...): the adapter library builds, loads and registers every op of
+    SURVEY.md §8(b); tensors that are not on the GPU are rejected by the dispatcher (the ops have
+    a CUDA/HIP implementation only -- there is no CPU fallback to fall into)."""
+    import pytest
+    import torch
+    native.build_torch_ops()
+    ops = native.torch_ops()
+    for name in ("spot_shift_and_sep", "spot_forward", "shift_norm_preproc", "energies", "pair_sisdr", "segment_sisdr",
+                 "center_rows_", "srp_phat_map", "sep_infer", "sep_forward"):
+        assert hasattr(ops, name), name
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ops.pair_sisdr(torch.zeros(2, 8))
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ops.energies(torch.zeros(2, 8), 4)
+
+
+def test_sep_argument_errors_do_not_need_a_gpu():
+    from ctypes import byref, c_void_p
+    L = native.lib()
+    cfg = native.SepConfigC()
+    h = c_void_p()
+    assert L.asw_sep_create(byref(cfg), byref(h)) == -1           # depth 0
+    assert b"depth" in L.asw_last_error()
+    assert L.asw_sep_infer(None, None, 7, 100, None, 2, None, None) == -1
+    assert L.asw_relpos_attention(None, None, None, None, 1, 10, 128, 8, 0.1, None, None) == -1
+    assert L.asw_add_layernorm2(None, None, 1.0, None, None, 4, 512, 1e-5, 0, None, None, None) == -1
+    assert L.asw_joint_shift_stats_scratch_doubles() > 0
