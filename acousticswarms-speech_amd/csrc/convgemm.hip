@@ -35,6 +35,8 @@
 // col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)), then each wave owns whole
 // rows: + residual, * gate tensor, LayerNorm over the row (two-pass, wave shuffles),
 // GroupNorm partial sums, coalesced row stores.
+#include <cstdlib>
+
 #include "asw_common.h"
 
 namespace {
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN)
 __attribute__((amdgpu_waves_per_eu(WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 ? 2 : 3) : 1))))
 void resconv16_kernel(const asw_convgemm_args p) {
   static_assert(QD == 2 || QD == 4, "B prefetch depth in k-steps");
-  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+  static_assert(WM * WN == 2 || WM * WN == 4 || WM * WN == 8, "2, 4 or 8 waves per workgroup");
   constexpr int NTHR = 64 * WM * WN, SROWS = NTHR / 16;   // staging: 16 threads per row
   constexpr int TM = BM / WM / 32, TN = C / WN / 32;
   constexpr int RS = 272;                    // bytes per staged row: 128 hi + 128 lo + 16 pad
@@ -701,7 +703,12 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
   // workgroup.  With the epilogue removed the same loops run at 355-385 TFLOP/s, the level of an
   // idealised k-step loop fed from L2 on random data (tests/micro/cu_probe.hip: 400).
   switch (a.N) {
-    case 64: return poly ? launch_res<128, 64, 2, 2, 4>(a, s) : launch_res<128, 64, 2, 2, 1>(a, s);
+    case 64: {
+      static const int v64 = getenv("ASW_RES64") ? atoi(getenv("ASW_RES64")) : 0;     // experiment switch
+      if (v64 == 1) return poly ? launch_res<256, 64, 4, 1, 4>(a, s) : launch_res<256, 64, 4, 1, 1>(a, s);
+      if (v64 == 2) return poly ? launch_res<256, 64, 2, 1, 4>(a, s) : launch_res<256, 64, 2, 1, 1>(a, s);
+      return poly ? launch_res<128, 64, 2, 2, 4>(a, s) : launch_res<128, 64, 2, 2, 1>(a, s);
+    }
     case 128: return poly ? launch_res<128, 128, 2, 2, 4, 2>(a, s) : launch_res<128, 128, 2, 2, 1, 2>(a, s);
     case 256: return poly ? launch_res<64, 256, 1, 4, 2>(a, s) : launch_res<64, 256, 1, 4, 1>(a, s);
     case 512:

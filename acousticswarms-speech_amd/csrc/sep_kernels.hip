@@ -331,39 +331,58 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
 // Inter-speaker attention: at every (item n, time step t, head h) the S speakers are the
 // sequence (nn.MultiheadAttention inside nn.TransformerEncoderLayer(batch_first), applied to
 // x.reshape(N*T, S, F), SpeakerSeparation/network.py:311-316).  qkv [N][S][L][3d] standard
-// layout with in_proj bias already added; ctx [N][S][L][d].  One wave per (n, t): lanes are the
-// head dimension (hd <= 64); lane s2 keeps score (s1, s2); S <= 64.
+// layout with in_proj bias already added; ctx [N][S][L][d].
+// One wave per (n, t, head): the S x hd blocks of q, k, v are staged once into LDS (rows padded
+// to hd+1 floats so the per-lane row walks are conflict free); lane s2 computes the scores
+// (s1, s2) for every s1 with an in-lane dot product, the softmax runs across lanes, and for the
+// output lane = head dimension.  S <= 64, hd <= 64.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void inter_attention_kernel(const float* __restrict__ qkv, int NB, int S, int L, int d,
-                                                              int nhead, float* __restrict__ ctx) {
-  const long nt = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (nt >= (long)NB * L) return;
+constexpr int IA_WAVES = 4;
+
+__global__ __launch_bounds__(64 * IA_WAVES) void inter_attention_kernel(const float* __restrict__ qkv, int NB, int S, int L,
+                                                                        int d, int nhead, float* __restrict__ ctx) {
+  extern __shared__ __align__(16) float smem[];
+  const int hd = d / nhead, ldk = hd + 1;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* Qs = smem + (size_t)wid * (3 * S * ldk + S * 64);     // per-wave region: Q, K, V [S][hd+1], P [S][64]
+  float* Ks = Qs + S * ldk;
+  float* Vs = Ks + S * ldk;
+  float* Ps = Vs + S * ldk;
+  long unit = (long)blockIdx.x * IA_WAVES + wid;                  // (n, t, h)
+  const bool active = unit < (long)NB * L * nhead;                // wave-uniform
+  if (!active) unit = 0;
+  const int h = (int)(unit % nhead);
+  const long nt = unit / nhead;
   const int n = (int)(nt / L), t = (int)(nt - (long)n * L);
-  const int hd = d / nhead;
   const float scale = 1.0f / sqrtf((float)hd);
-  const bool on = lane < hd;
-  for (int h = 0; h < nhead; ++h) {
-    for (int s1 = 0; s1 < S; ++s1) {
-      const long r1 = ((long)(n * S + s1) * L + t);
-      const float qv = on ? qkv[r1 * 3 * d + h * hd + lane] * scale : 0.f;
-      float mine = -INFINITY;                                   // lane s2 keeps score (s1, s2)
-      for (int s2 = 0; s2 < S; ++s2) {
-        const long r2 = ((long)(n * S + s2) * L + t);
-        const float kv = on ? qkv[r2 * 3 * d + d + h * hd + lane] : 0.f;
-        const float dot = wsum(qv * kv);
-        if (lane == s2) mine = dot;
-      }
-      const float mx = wmax(mine);
-      const float e = lane < S ? expf(mine - mx) : 0.f;
-      const float p = e / wsum(e);
+  for (int i = lane; active && i < S * hd; i += 64) {
+    const int s = i / hd, c = i - s * hd;
+    const float* row = qkv + ((long)(n * S + s) * L + t) * 3 * d + h * hd + c;
+    Qs[s * ldk + c] = row[0] * scale;
+    Ks[s * ldk + c] = row[d];
+    Vs[s * ldk + c] = row[2 * d];
+  }
+  __syncthreads();
+  for (int s1 = 0; active && s1 < S; ++s1) {
+    float sc = -INFINITY;
+    if (lane < S) {
       float acc = 0.f;
-      for (int s2 = 0; s2 < S; ++s2) {
-        const long r2 = ((long)(n * S + s2) * L + t);
-        const float vv = on ? qkv[r2 * 3 * d + 2 * d + h * hd + lane] : 0.f;
-        acc = fmaf(__shfl(p, s2, 64), vv, acc);
-      }
-      if (on) ctx[r1 * d + h * hd + lane] = acc;
+      const float* qr = Qs + s1 * ldk;
+      const float* kr = Ks + lane * ldk;
+      for (int c = 0; c < hd; ++c) acc = fmaf(qr[c], kr[c], acc);
+      sc = acc;
+    }
+    const float mx = wmax(sc);
+    const float e = lane < S ? expf(sc - mx) : 0.f;
+    const float p = e / wsum(e);
+    Ps[s1 * 64 + lane] = p;
+  }
+  __syncthreads();
+  if (active && lane < hd) {
+    for (int s1 = 0; s1 < S; ++s1) {
+      float acc = 0.f;
+      for (int s2 = 0; s2 < S; ++s2) acc = fmaf(Ps[s1 * 64 + s2], Vs[s2 * ldk + lane], acc);
+      ctx[((long)(n * S + s1) * L + t) * d + h * hd + lane] = acc;
     }
   }
 }
@@ -464,8 +483,13 @@ extern "C" int asw_inter_attention(const float* qkv, int NB, int S, int L, int d
   ASW_CHECK_ARG(qkv && ctx, "inter_attention: null pointer");
   ASW_CHECK_ARG(NB > 0 && S > 0 && S <= 64 && L > 0 && nhead > 0 && d % nhead == 0 && d / nhead <= 64,
                 "inter_attention: bad shape (S <= 64, head_dim <= 64)");
-  dim3 grid(asw::cdiv((long)NB * L, 4));
-  hipLaunchKernelGGL(inter_attention_kernel, grid, dim3(256), 0, asw::as_stream(stream), qkv, NB, S, L, d, nhead, ctx);
+  const int hd = d / nhead;
+  const size_t smem = sizeof(float) * (size_t)IA_WAVES * (3 * (size_t)S * (hd + 1) + (size_t)S * 64);
+  static asw::SmemAttr attr;                                   // per device
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(inter_attention_kernel), smem)) return rc;
+  dim3 grid(asw::cdiv((long)NB * L * nhead, IA_WAVES));
+  hipLaunchKernelGGL(inter_attention_kernel, grid, dim3(64 * IA_WAVES), smem, asw::as_stream(stream), qkv, NB, S, L, d, nhead,
+                     ctx);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }

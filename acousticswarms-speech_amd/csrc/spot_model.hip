@@ -59,12 +59,22 @@ struct asw_spot {
   int byp_k = 0;                           // padded K of the bypass GEMM
   std::map<std::pair<float, float>, std::unique_ptr<GateSet>> gates;
 
-  // workspace
-  char* ws = nullptr;
-  size_t ws_bytes = 0;
+  // workspace: one arena per lane.  With two lanes consecutive internal batches run on two HIP
+  // streams (the caller's and a side stream), so the memory-bound passes and the launch tails of
+  // one batch overlap the MFMA kernels of the other.
+  char* ws[2] = {nullptr, nullptr};
+  size_t ws_bytes[2] = {0, 0};
+  int lanes = 1;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::map<std::string, Tap> taps;
 
-  ~asw_spot() { if (ws) (void)hipFree(ws); }
+  ~asw_spot() {
+    for (char* w : ws) if (w) (void)hipFree(w);
+    if (side) (void)hipStreamDestroy(side);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+  }
 };
 
 namespace {
@@ -249,17 +259,17 @@ void layout(const asw_spot* m, int B, int T, Arena& a, Plan& pl) {
   pl.escr = a.take<double>((size_t)B * (T + 1));
 }
 
-int ensure_ws(asw_spot* m, int B, int T, Plan& pl) {
+int ensure_ws(asw_spot* m, int B, int T, Plan& pl, int lane = 0) {
   Arena dry(nullptr, 0, true);
   layout(m, B, T, dry, pl);
   const size_t need = dry.off + 4096;
-  if (need > m->ws_bytes) {
-    if (m->ws) { ASW_HIP(hipDeviceSynchronize()); (void)hipFree(m->ws); m->ws = nullptr; m->ws_bytes = 0; }
-    if (hipMalloc(&m->ws, need) != hipSuccess)
+  if (need > m->ws_bytes[lane]) {
+    if (m->ws[lane]) { ASW_HIP(hipDeviceSynchronize()); (void)hipFree(m->ws[lane]); m->ws[lane] = nullptr; m->ws_bytes[lane] = 0; }
+    if (hipMalloc(&m->ws[lane], need) != hipSuccess)
       return asw::set_error(ASW_ERR_NOMEM, "workspace of %.1f MiB for batch %d, T=%d", need / 1048576.0, B, T);
-    m->ws_bytes = need;
+    m->ws_bytes[lane] = need;
   }
-  Arena real(m->ws, m->ws_bytes, false);
+  Arena real(m->ws[lane], m->ws_bytes[lane], false);
   layout(m, B, T, real, pl);
   return ASW_OK;
 }
@@ -524,22 +534,49 @@ extern "C" int asw_spot_shift_and_sep(asw_spot* m, const float* mix, int M, int 
   GateSet* gs = nullptr;
   if ((rc = get_gates(m, strict == 1 ? 1.f : 0.f, strict == 1 ? 0.f : 1.f, &gs))) return rc;
   const int Bmax = N < m->batch ? N : m->batch;
-  Plan pl;
-  if ((rc = ensure_ws(m, Bmax, T, pl))) return rc;
-  const int C = m->cfg.channels, pad_l = m->cfg.encoder_kernel_size / 2;
-  for (int i0 = 0; i0 < N; i0 += Bmax) {
-    const int B = N - i0 < Bmax ? N - i0 : Bmax;
-    pl.B = B;
-    const int32_t* off = offsets + (size_t)i0 * (M - 1);
-    ASW_HIP(hipMemsetAsync(pl.refn, 0, (size_t)B * pl.RL * sizeof(float), s));
-    if ((rc = asw_shift_stats(mix, M, T, off, B, circular, pl.mean, pl.stdv, s))) return rc;
-    if ((rc = asw_shift_norm_preproc(mix, M, T, pl.Tp, off, B, circular, pl.mean, pl.stdv, m->pre_w.p, m->pre_b.p, C,
-                                     pl.X[0], pl.refn + pad_l, pl.RL, s)))
-      return rc;
-    float* y = out_wave ? out_wave + (size_t)i0 * T : pl.ywave;
-    if ((rc = run_network(m, pl, gs, pl.mean, pl.stdv, y, s))) return rc;
-    if (out_energy && (rc = asw_energies(y, B, T, energy_window, pl.escr, out_energy + (size_t)i0 * 2, s))) return rc;
+  const int n_batches = (N + Bmax - 1) / Bmax;
+  const int lanes = (m->lanes == 2 && n_batches >= 2) ? 2 : 1;
+  Plan pl[2];
+  for (int l = 0; l < lanes; ++l)
+    if ((rc = ensure_ws(m, Bmax, T, pl[l], l))) return rc;
+  hipStream_t st[2] = {s, s};
+  if (lanes == 2) {
+    if (!m->side) {
+      ASW_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+      ASW_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+      ASW_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
+    st[1] = m->side;
+    ASW_HIP(hipEventRecord(m->ev_fork, s));                // the side lane starts after everything queued before this call
+    ASW_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
   }
+  const int C = m->cfg.channels, pad_l = m->cfg.encoder_kernel_size / 2;
+  int k = 0;
+  for (int i0 = 0; i0 < N; i0 += Bmax, ++k) {
+    const int B = N - i0 < Bmax ? N - i0 : Bmax;
+    Plan& p = pl[k % lanes];
+    hipStream_t q = st[k % lanes];
+    p.B = B;
+    const int32_t* off = offsets + (size_t)i0 * (M - 1);
+    ASW_HIP(hipMemsetAsync(p.refn, 0, (size_t)B * p.RL * sizeof(float), q));
+    if ((rc = asw_shift_stats(mix, M, T, off, B, circular, p.mean, p.stdv, q))) return rc;
+    if ((rc = asw_shift_norm_preproc(mix, M, T, p.Tp, off, B, circular, p.mean, p.stdv, m->pre_w.p, m->pre_b.p, C,
+                                     p.X[0], p.refn + pad_l, p.RL, q)))
+      return rc;
+    float* y = out_wave ? out_wave + (size_t)i0 * T : p.ywave;
+    if ((rc = run_network(m, p, gs, p.mean, p.stdv, y, q))) return rc;
+    if (out_energy && (rc = asw_energies(y, B, T, energy_window, p.escr, out_energy + (size_t)i0 * 2, q))) return rc;
+  }
+  if (lanes == 2) {                                         // the caller's stream continues after both lanes
+    ASW_HIP(hipEventRecord(m->ev_join, m->side));
+    ASW_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
+  }
+  return ASW_OK;
+}
+
+extern "C" int asw_spot_set_lanes(asw_spot* m, int lanes) {
+  ASW_CHECK_ARG(m && (lanes == 1 || lanes == 2), "set_lanes: 1 or 2");
+  m->lanes = lanes;
   return ASW_OK;
 }
 

@@ -111,6 +111,76 @@ def get_items(path):
     return metadata, mix, np.stack(gt) if gt else np.zeros((0, mix.shape[1]), dtype=np.float32)
 
 
+# ---- separation metrics ------------------------------------------------------------------------
+def _project(reference_sources, estimated_source, flen):
+    """Least-squares projection of ``estimated_source`` on the span of the references delayed by
+    0..flen-1 samples (BSS-eval "mtifilt" decomposition, Vincent et al. 2006), solved through
+    FFT-computed auto / cross-correlations and one (nsrc*flen)-square linear system."""
+    from scipy.linalg import toeplitz
+    from scipy.signal import fftconvolve
+    nsrc, nsampl = reference_sources.shape
+    ref = np.hstack((reference_sources, np.zeros((nsrc, flen - 1))))
+    est = np.hstack((estimated_source, np.zeros(flen - 1)))
+    n_fft = int(2 ** np.ceil(np.log2(nsampl + flen - 1.0)))
+    sf = np.fft.fft(ref, n=n_fft, axis=1)
+    sef = np.fft.fft(est, n=n_fft)
+    G = np.zeros((nsrc * flen, nsrc * flen))
+    for i in range(nsrc):
+        for j in range(i, nsrc):
+            ssf = np.real(np.fft.ifft(sf[i] * np.conj(sf[j])))
+            ss = toeplitz(np.hstack((ssf[0], ssf[-1:-flen:-1])), r=ssf[:flen])
+            G[i * flen:(i + 1) * flen, j * flen:(j + 1) * flen] = ss
+            G[j * flen:(j + 1) * flen, i * flen:(i + 1) * flen] = ss.T
+    D = np.zeros(nsrc * flen)
+    for i in range(nsrc):
+        ssef = np.real(np.fft.ifft(sf[i] * np.conj(sef)))
+        D[i * flen:(i + 1) * flen] = np.hstack((ssef[0], ssef[-1:-flen:-1]))
+    try:
+        C = np.linalg.solve(G, D).reshape(flen, nsrc, order="F")
+    except np.linalg.LinAlgError:
+        C = np.linalg.lstsq(G, D, rcond=None)[0].reshape(flen, nsrc, order="F")
+    sproj = np.zeros(nsampl + flen - 1)
+    for i in range(nsrc):
+        sproj += fftconvolve(C[:, i], ref[i])[:nsampl + flen - 1]
+    return sproj
+
+
+def bss_eval_sdr(reference_sources, estimated_sources, flen: int = 512):
+    """Signal-to-distortion ratio of estimate j against reference j with a 512-tap
+    time-invariant distortion filter allowed -- the quantity the reference takes from
+    ``mir_eval.separation.bss_eval_sources(..., compute_permutation=False)``
+    (sep/eval/get_items.py:50-52).  mir_eval is absent from the image and unpinned upstream; this
+    is a restatement of the published BSS-eval v3 algorithm: "parity unpinned"."""
+    ref = np.atleast_2d(np.asarray(reference_sources, dtype=np.float64))
+    est = np.atleast_2d(np.asarray(estimated_sources, dtype=np.float64))
+    if ref.shape != est.shape:
+        raise ValueError(f"reference {ref.shape} and estimate {est.shape} shapes differ")
+    out = np.zeros(ref.shape[0])
+    for j in range(ref.shape[0]):
+        nsampl = est.shape[1]
+        s_true = np.hstack((ref[j], np.zeros(flen - 1)))
+        e_spat = _project(ref[j:j + 1], est[j], flen) - s_true
+        e_interf = _project(ref, est[j], flen) - s_true - e_spat
+        e_artif = -s_true - e_spat - e_interf
+        e_artif[:nsampl] += est[j]
+        num, den = np.sum((s_true + e_spat) ** 2), np.sum((e_interf + e_artif) ** 2)
+        out[j] = np.inf if den == 0 else 10 * np.log10(num / den)
+    return out
+
+
+def compute_metrics(input_signal, est_signal, gt):
+    """(input_sdr, output_sdr, input_sisdr, output_sisdr) per matched talker, as
+    sep/eval/get_items.py:46-70 with permute=False: BSS-eval SDR and SI-SDR of the unprocessed
+    reference-microphone signal and of the separated output against the ground truth."""
+    gt = np.asarray(gt, dtype=np.float64)
+    inp = np.asarray(input_signal, dtype=np.float64)
+    est = np.asarray(est_signal, dtype=np.float64)
+    input_sdr, output_sdr = bss_eval_sdr(gt, inp), bss_eval_sdr(gt, est)
+    input_sisdr = [si_sdr(inp[i], gt[i]) for i in range(gt.shape[0])]
+    output_sisdr = [si_sdr(est[i], gt[i]) for i in range(gt.shape[0])]
+    return input_sdr, output_sdr, input_sisdr, output_sisdr
+
+
 # ---- one sample --------------------------------------------------------------------------------
 def evaluate_sample(model, metadata, mix, gt):
     """Run ``model`` (a ``JointModel``) on one sample and build the reference's result record
@@ -131,16 +201,22 @@ def evaluate_sample(model, metadata, mix, gt):
     for s in range(gt_pos.shape[0]):
         rec["gt"].append({"sample": offsets_gt[:, s].tolist(), "pos": gt_pos[s].tolist()})
     unmatched = list(range(n_out))
-    for out_id, s in perm:
+    if perm:
+        # matched pairs in the reference's order (eval_model.py:162-187): separated output (joint
+        # decoder when attached), localisation-stage output, ground truth, unprocessed mic 0
+        pa = np.array(perm)
+        ref_sig = np.repeat(mix[0:1].astype(np.float64), len(perm), axis=0)
+        in_sdr, out_sdr, in_sisdr_l, out_sisdr_l = compute_metrics(ref_sig, sep_audio[pa[:, 0]], gt[pa[:, 1]])
+    for i, (out_id, s) in enumerate(perm):
         unmatched.remove(out_id)
-        in_sisdr = si_sdr(mix[0].astype(np.float64), gt[s].astype(np.float64))
+        in_sisdr = in_sisdr_l[i]
         rec["pred"].append({
             "voice_id": s, "shifts": est_off[out_id].tolist(), "pos": est_pos[out_id].tolist(),
             "sample_err": float(np.mean(np.abs(est_off[out_id] - offsets_gt[:, s]))),
             "dis_err": float(np.linalg.norm(est_pos[out_id][:2] - gt_pos[s][:2])),
-            "si_snr_in_mir": None, "si_snri_mir": None,          # mir_eval BSS-eval: not restated
+            "si_snr_in_mir": float(in_sdr[i]), "si_snri_mir": float(out_sdr[i] - in_sdr[i]),   # BSS-eval SDR (restated)
             "si_snr_in": in_sisdr,
-            "si_snri": si_sdr(sep_audio[out_id].astype(np.float64), gt[s].astype(np.float64)) - in_sisdr,
+            "si_snri": out_sisdr_l[i] - in_sisdr,
             "si_snr_in_old": in_sisdr,
             "si_snri_old": si_sdr(audio_loc[out_id].astype(np.float64), gt[s].astype(np.float64)) - in_sisdr})
     for rid in unmatched:

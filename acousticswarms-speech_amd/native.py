@@ -136,6 +136,7 @@ SIGNATURES = {
     "asw_spot_finalize": (c_int, [c_void_p]),
     "asw_spot_set_batch": (c_int, [c_void_p, c_int]),
     "asw_spot_set_precision": (c_int, [c_void_p, c_int]),
+    "asw_spot_set_lanes": (c_int, [c_void_p, c_int]),
     "asw_split_weights_f16": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_int32)]),
     "asw_pack_fragments_f16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_int32)]),
     "asw_spot_shift_and_sep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,

@@ -32,7 +32,8 @@ def offsets_from_patches(patch_list, n_pairs: int) -> np.ndarray:
 class SpotModel:
     PRECISIONS = {"f32": 0, "f16x3": 1}
 
-    def __init__(self, cfg: SpotConfig = FULL, state_dict=None, batch_size: int = 32, precision: str = "f32"):
+    def __init__(self, cfg: SpotConfig = FULL, state_dict=None, batch_size: int = 32, precision: str = "f32",
+                 lanes: int = 1):
         """precision: "f32" = exact fp32 MFMA; "f16x3" = split-operand half MFMA with fp32
         accumulation (~21-bit operands, 5.3x the f32 matrix rate), see csrc/convgemm.hip."""
         if precision not in self.PRECISIONS:
@@ -40,6 +41,7 @@ class SpotModel:
         self.cfg = cfg
         self.precision = precision
         self.batch_size = batch_size
+        self.lanes = int(lanes)             # 2: consecutive internal batches on two HIP streams (asw_spot_set_lanes)
         self.device = None
         self._h = None
         self._sd = None
@@ -96,6 +98,7 @@ class SpotModel:
         self._h = h
         native.check(L.asw_spot_set_batch(self._h, int(self.batch_size)))
         native.check(L.asw_spot_set_precision(self._h, self.PRECISIONS[self.precision]))
+        native.check(L.asw_spot_set_lanes(self._h, self.lanes))
         self.device = device
         if self._sd is not None:
             self._upload()
@@ -110,6 +113,11 @@ class SpotModel:
         self.precision = precision
         if self._h is not None:
             native.check(native.lib().asw_spot_set_precision(self._h, self.PRECISIONS[precision]))
+
+    def set_lanes(self, lanes: int):
+        self.lanes = int(lanes)
+        if self._h is not None:
+            native.check(native.lib().asw_spot_set_lanes(self._h, self.lanes))
 
     def set_batch_size(self, b: int):
         self.batch_size = int(b)

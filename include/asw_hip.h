@@ -81,6 +81,13 @@ int asw_spot_finalize(asw_spot* m);
  * spot_batch_size, sep/training/JointModel/network.py:28,75). */
 int asw_spot_set_batch(asw_spot* m, int batch);
 
+/* Number of execution lanes (1 or 2, default 1).  With 2, consecutive internal batches of one
+ * asw_spot_shift_and_sep call run on two HIP streams (the caller's stream and a library-owned
+ * side stream, forked and joined with events inside the call) with one workspace each, so the
+ * memory-bound passes and the launch tails of one batch overlap the MFMA kernels of the other.
+ * Results are identical; the call still only depends on, and is ordered by, the caller's stream. */
+int asw_spot_set_lanes(asw_spot* m, int lanes);
+
 /* Arithmetic of the GEMM-class layers: 0 = exact fp32 MFMA (default), 1 = "f16x3"
  * split-operand half MFMA with fp32 accumulation (see asw_convgemm_args.precision). */
 int asw_spot_set_precision(asw_spot* m, int precision);

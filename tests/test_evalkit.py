@@ -94,3 +94,81 @@ def test_sample_directory_round_trip_and_record(tmp_path):
         assert {"voice_id", "shifts", "pos", "sample_err", "dis_err", "si_snr_in", "si_snri", "si_snr_in_old",
                 "si_snri_old"} <= set(p)
     json.dumps(rec)                                                    # serialisable as the reference writes it
+
+
+def test_bss_eval_sdr_properties():
+    """BSS-eval SDR (restated; mir_eval absent -> parity unpinned): invariant to a short FIR
+    filtering of the target, equal to the SNR for white noise, and the interference term uses the
+    other references."""
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(3)
+    ref = rng.standard_normal((2, 6000))
+    # a filtered copy of the target is "distortion-free" up to the allowed filter (what is left is
+    # the two-sample tail the truncated FIR output lacks: ~ -50 dB at this length); a pure gain is exact
+    est = np.stack([lfilter([0.9, 0.3, -0.2], [1.0], ref[0]), 0.5 * ref[1]])
+    sdr = evalkit.bss_eval_sdr(ref, est, flen=64)
+    assert sdr[0] > 40 and sdr[1] > 100
+    # additive white noise at 10 dB SNR
+    noise = rng.standard_normal(6000)
+    noise *= np.linalg.norm(ref[0]) / np.linalg.norm(noise) / np.sqrt(10.0)
+    sdr = evalkit.bss_eval_sdr(ref[:1], (ref[0] + noise)[None], flen=64)
+    assert abs(sdr[0] - 10.0) < 0.5
+    # leakage of the other talker counts as distortion
+    sdr = evalkit.bss_eval_sdr(ref, np.stack([ref[0] + 0.1 * ref[1], ref[1]]), flen=64)
+    assert 18.0 < sdr[0] < 22.0 and sdr[1] > 100
+    ins, outs, isi, osi = evalkit.compute_metrics(np.stack([ref[0] + ref[1]] * 2), ref + 0.01 * rng.standard_normal(ref.shape), ref)
+    assert np.all(np.asarray(outs) > np.asarray(ins) + 20) and np.all(np.asarray(osi) > np.asarray(isi) + 20)
+
+
+def test_experiment_directory_loading(tmp_path):
+    """load_model_from_exp (sep/helpers/utils.py:165-215): description.json -> network, best /
+    last checkpoint selection, nothing unpickled."""
+    import torch
+    from acousticswarms_speech_amd.config import SEP_SMALL, SMALL
+    from acousticswarms_speech_amd.experiment import config_from_description, load_model_from_exp
+    from acousticswarms_speech_amd.weights import make_sep_state_dict, make_spot_state_dict
+    # the reference's own description files
+    kind, cfg = config_from_description({"model_name": "SpeakerLocalization", "model_params": {
+        "n_mics": 7, "channels": 64, "growth": 2, "encoder_channels": 2048, "stride_list": [2, 2, 4, 4, 4],
+        "kernel_size": 7, "residual_dilation_factor": 7}})
+    assert kind == "spot" and cfg.stride_list == (2, 2, 4, 4, 4) and cfg.encoder_channels == 2048
+    kind, cfg = config_from_description({"model_name": "SpeakerSeparation", "model_params": {
+        "n_mics": 7, "max_speakers": 5, "channels": 64, "growth": 2, "encoder_channels": 4096}})
+    assert kind == "sep" and cfg.max_speakers == 5 and cfg.stride_list == (2, 2, 4, 4) and cfg.encoder_channels == 4096
+    # spot experiment with two checkpoints and a loadable state.pt -> 'best' picks epoch 1
+    exp = tmp_path / "loc"
+    (exp / "checkpoints").mkdir(parents=True)
+    params = {"n_mics": 7, "kernel_size": 7, "stride_list": list(SMALL.stride_list), "channels": SMALL.channels, "growth": 2,
+              "encoder_channels": SMALL.encoder_channels, "ffw_dim": SMALL.ffw_dim}
+    (exp / "description.json").write_text(json.dumps({"model_name": "SpeakerLocalization", "model_params": params}))
+    for ep in (0, 1, 2):
+        sd = {k: torch.from_numpy(v) for k, v in make_spot_state_dict(SMALL, seed=100 + ep).items()}
+        torch.save(sd, exp / "checkpoints" / f"loc_{ep}.pt")
+    torch.save({"val_losses": [0.9, 0.2, 0.5]}, exp / "checkpoints" / "state.pt")
+    with redirect_stdout(io.StringIO()):
+        m = load_model_from_exp(str(exp), mode="best")
+    np.testing.assert_array_equal(m._sd["preproc.weight"], make_spot_state_dict(SMALL, seed=101)["preproc.weight"])
+    with redirect_stdout(io.StringIO()):
+        m = load_model_from_exp(str(exp), mode="last")
+    np.testing.assert_array_equal(m._sd["preproc.weight"], make_spot_state_dict(SMALL, seed=102)["preproc.weight"])
+    # separation experiment without state.pt: falls back to 'last'; 'new' loads nothing
+    exp2 = tmp_path / "sepexp"
+    (exp2 / "checkpoints").mkdir(parents=True)
+    sparams = {"n_mics": 7, "max_speakers": 5, "stride_list": list(SEP_SMALL.stride_list), "channels": 64, "growth": 2,
+               "encoder_channels": SEP_SMALL.encoder_channels, "ffw_dim": SEP_SMALL.ffw_dim,
+               "bottleneck_layers": SEP_SMALL.bottleneck_layers, "bottleneck_ksize": SEP_SMALL.bottleneck_ksize}
+    (exp2 / "description.json").write_text(json.dumps({"model_name": "SpeakerSeparation", "model_params": sparams}))
+    torch.save({k: torch.from_numpy(v) for k, v in make_sep_state_dict(SEP_SMALL, seed=7).items()},
+               exp2 / "checkpoints" / "sepexp_4.pt")
+    with redirect_stdout(io.StringIO()) as out:
+        m2 = load_model_from_exp(str(exp2), mode="best")
+    assert "WARNING" in out.getvalue() and m2._sd is not None and m2.cfg == SEP_SMALL
+    with redirect_stdout(io.StringIO()):
+        assert load_model_from_exp(str(exp2), mode="new")._sd is None
+    # a wrong key set is rejected (strict)
+    bad = {k: torch.from_numpy(v) for k, v in make_sep_state_dict(SEP_SMALL, seed=7).items()}
+    bad.pop("preproc.bias")
+    torch.save(bad, exp2 / "checkpoints" / "sepexp_9.pt")
+    import pytest
+    with pytest.raises(RuntimeError), redirect_stdout(io.StringIO()):
+        load_model_from_exp(str(exp2), mode="last")

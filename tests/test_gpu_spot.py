@@ -269,3 +269,23 @@ def test_edge_shapes_vs_oracle(M, T):
             per = [snr_db(y[i], ref[i]) for i in range(n)]
             assert min(per) > 80.0, (M, T, n, strict, per)
     _log(f"edge shapes M={M} T={T}: ok")
+
+
+def test_two_lanes_give_the_single_lane_result():
+    """asw_spot_set_lanes(2): consecutive internal batches on two HIP streams with one workspace
+    each -- bit-identical waveforms and energies, ragged last batch included, and the call stays
+    ordered by the caller's stream (the result is read right after it on that stream)."""
+    from acousticswarms_speech_amd.config import SMALL
+    from acousticswarms_speech_amd.scenes import make_scene, random_offsets
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    sd = make_spot_state_dict(SMALL, seed=3)
+    mix = torch.from_numpy(make_scene(7, 2, 7, 6000).mix).cuda()
+    offs = torch.from_numpy(random_offsets(3, 37, 6, 140)).cuda()
+    for prec in ("f32", "f16x3"):
+        one = SpotModel(SMALL, sd, batch_size=8, precision=prec, lanes=1).to("cuda")
+        two = SpotModel(SMALL, sd, batch_size=8, precision=prec, lanes=2).to("cuda")
+        w1, e1 = one.shift_and_sep_device(mix, offs, strict=1, want_wave=True, want_energy=True, window=1000)
+        for _ in range(3):
+            w2, e2 = two.shift_and_sep_device(mix, offs, strict=1, want_wave=True, want_energy=True, window=1000)
+            assert torch.equal(w1, w2) and torch.equal(e1, e2)
