@@ -51,6 +51,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// f16x3 range guard.  In the f16x3 mode activations are split into fp16 halves while they are
+// staged, which saturates at +-65504.  Every tensor a GEMM reads is either normalised
+// (LayerNorm / GroupNorm output, bounded by |gamma| sqrt(C) + |beta|) or the un-normalised output
+// of a plain epilogue (the masked latent, the feed-forward intermediate).  The plain epilogue
+// therefore counts, in f16x3 mode, the threads that wrote a value beyond the fp16 range;
+// asw_f16x3_overflow_count() reads the counter.  Zero on every test and bench run with seeded
+// weights; a non-zero count means the next GEMM clipped its input and the f32 mode must be used.
+__device__ unsigned int g_f16x3_overflow = 0;
+
 // ------------------------------------------------------------------ shared epilogue
 // tile row -> output row of the batch item (or -1): contiguous tiles
 struct RowsContig {
@@ -61,7 +70,7 @@ struct RowsContig {
 template <int BM, int BN, int WM, int WN, bool LN, bool STATS, bool RESID, bool MUL, typename RowMap>
 __device__ __forceinline__ void epilogue(  // WM*WN waves (4 or 8)
 floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
-                                         float* smem, float acc_scale, const RowMap& rowmap, const dim3 tile) {
+                                         float* smem, float acc_scale, const RowMap& rowmap, const dim3 tile, const int ncol) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDC = BN + 4;
   float* Ct = smem;
@@ -70,6 +79,8 @@ floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
   const int b = tile.z, n0 = tile.y * BN;
   float st0 = 0.f, sq0 = 0.f, st1 = 0.f, sq1 = 0.f;
   const int half_mod = p.chan_mod >> 1;
+  const bool guard = !LN && !STATS && p.precision == 1;       // un-normalised output that a later f16x3 GEMM may read
+  float amax = 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     __syncthreads();
@@ -170,12 +181,17 @@ floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
               const float s1 = (x.x + x.y) + (x.z + x.w), s2 = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
               if (((n0 + col) % p.chan_mod) >= half_mod) { st1 += s1; sq1 += s2; } else { st0 += s1; sq0 += s2; }
             }
+            if (!LN && !STATS) {
+              const float4 x = v[u][q];
+              amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
+            }
             *reinterpret_cast<float4*>(p.out + obase[u] + col) = v[u][q];
           }
         }
       }
     }
   }
+  if (guard && !(amax <= 65504.f)) atomicAdd(&g_f16x3_overflow, 1u);      // also catches NaN
   if (STATS) {
     __syncthreads();
     st0 = wave_sum(st0); sq0 = wave_sum(sq0); st1 = wave_sum(st1); sq1 = wave_sum(sq1);
@@ -188,7 +204,7 @@ floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
       for (int w = 0; w < WM * WN; ++w) s += red[w * 4 + tid];
       // slot layout is independent of the tile shape: stats_stride slots per batch item (the
       // launcher zero-fills the buffer, smaller grids simply leave slots at zero)
-      const long part = (long)b * p.stats_stride + (long)tile.x * gridDim.y + tile.y;
+      const long part = (long)b * p.stats_stride + (long)tile.x * ncol + tile.y;
       p.stats[part * 4 + tid] = s;
     }
   }
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const asw_convgemm_args p
       }
     }
   }
-  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, 1.0f, RowsContig{m0, p.M_out}, blockIdx);
+  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, 1.0f, RowsContig{m0, p.M_out}, blockIdx, gridDim.y);
 }
 
 // ------------------------------------------------------------------ f16x3 split MFMA
@@ -363,9 +379,17 @@ __global__ __launch_bounds__(64 * WM * WN) void convgemm16_kernel(const asw_conv
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  // (An XCD-aware tile order -- each XCD taking a contiguous eighth of the tile sequence so its
-  // L2 sees compact A x W blocks -- was measured twice: no change, 327 vs 323 TFLOP/s.)
-  const dim3 tile = blockIdx;
+  // XCD-aware tile order.  The grid is 1-D; workgroup L goes to XCD L % 8 (the dispatcher deals
+  // consecutive workgroups round-robin over the 8 XCDs, each with its own L2).  Slot s = L / 8 of
+  // one XCD walks the column tiles of a row tile first: the ncol workgroups that read the same
+  // activation rows run back to back on ONE L2, so those rows come from HBM once instead of once
+  // per column tile.  The (batch item, row tile) pairs are dealt to the XCDs in groups of 8, so
+  // every XCD gets the same share whatever the number of row tiles per item; padded slots exit.
+  const int ncol = p.N / BN, nrt = (p.M_out + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int R = (slot / ncol) * 8 + xcd;                      // (batch item, row tile) index
+  if (R >= p.B * nrt) return;
+  const dim3 tile(R % nrt, slot % ncol, R / nrt);
   const int b = tile.z, m0 = tile.x * BM, n0 = tile.y * BN;
   const int K = p.taps * p.Cin;
   const int cpb = p.Cin / BK;
@@ -490,7 +514,7 @@ __global__ __launch_bounds__(64 * WM * WN) void convgemm16_kernel(const asw_conv
     if (kc + 1 < nk) gload(kc + 1, ra0, rbh0, rbl0);
     compute();
   }
-  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out}, tile);
+  epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out}, tile, ncol);
 }
 
 // ------------------------------------------------------------------ halo-staged residual conv
@@ -649,7 +673,7 @@ void resconv16_kernel(const asw_convgemm_args p) {
     }
   }
   epilogue<BM, C, WM, WN, true, false, true, false>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
-                                       ResRows<BM, PH>{m0, jb, pb, dil, T}, blockIdx);
+                                       ResRows<BM, PH>{m0, jb, pb, dil, T}, blockIdx, gridDim.y);
 }
 
 template <int BM, int C, int WM, int WN, int PH, int QD = 4>
@@ -734,6 +758,7 @@ int launch(const asw_convgemm_args& a, hipStream_t s) {
   ASW_CHECK_ARG(a.Cin % BK == 0, "convgemm: Cin=%d not a multiple of BK=%d", a.Cin, BK);
   ASW_CHECK_ARG(a.N % BN == 0, "convgemm: N=%d not a multiple of BN=%d", a.N, BN);
   dim3 grid(asw::cdiv(a.M_out, BM), a.N / BN, a.B);
+  if constexpr (F16) grid = dim3((((long)grid.x * a.B + 7) / 8) * 8 * grid.y, 1, 1);   // XCD-aware 1-D order, see the kernel
   std::string pn = asw::prof_name(F16 ? (MUL ? "convgemm16m" : "convgemm16") : (MUL ? "convgemm_m" : "convgemm"),
                                   BM, BN, BK, LN, STATS);
   if (asw::prof_detail()) {
@@ -769,6 +794,18 @@ inline int wide_tile_kind(int B, int M_out, int N, int K) {
 }
 
 }  // namespace
+
+extern "C" int asw_f16x3_overflow_count(int reset, uint32_t* count) {
+  ASW_CHECK_ARG(count != nullptr, "f16x3_overflow_count: null pointer");
+  unsigned int v = 0;
+  ASW_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16x3_overflow), sizeof v));      // waits for the device
+  if (reset && v) {
+    const unsigned int z = 0;
+    ASW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_f16x3_overflow), &z, sizeof z));
+  }
+  *count = v;
+  return ASW_OK;
+}
 
 extern "C" int asw_convgemm_stats_tiles(int M_out, int N) {
   // upper bound over the tile choices of both precisions (the smallest tiles)

@@ -168,6 +168,7 @@ SIGNATURES = {
                                 c_void_p, c_long, c_void_p]),
     "asw_convgemm_f32": (c_int, [POINTER(ConvGemmArgs), c_void_p]),
     "asw_convgemm_stats_tiles": (c_int, [c_int, c_int]),
+    "asw_f16x3_overflow_count": (c_int, [c_int, POINTER(c_int32)]),
     "asw_gn_glu": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                            c_void_p]),
     "asw_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -221,3 +221,12 @@ def inter_attention(qkv, nhead):
     ctx = torch.empty((NB, S, L, d), dtype=torch.float32, device=qkv.device)
     check(lib().asw_inter_attention(ptr(_f32(qkv)), NB, S, L, d, nhead, ptr(ctx), current_stream()))
     return ctx
+
+
+def f16x3_overflow_count(reset=True) -> int:
+    """Threads of f16x3 launches that produced an activation beyond the fp16 range since the last
+    reset (asw_f16x3_overflow_count); 0 means no later GEMM clipped its input."""
+    import ctypes
+    c = ctypes.c_int32()
+    check(lib().asw_f16x3_overflow_count(int(reset), byref(c)))
+    return int(c.value) & 0xFFFFFFFF

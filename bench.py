@@ -290,6 +290,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(last).all()
+    from acousticswarms_speech_amd.ops import f16x3_overflow_count
+    overflow = f16x3_overflow_count(reset=True)         # f16x3 range guard over warm-up + timed steps
+    if overflow:
+        raise SystemExit(f"f16x3 range guard: {overflow} activations beyond the fp16 range; rerun with --precision f32")
 
     # ---- extra legs (every rank takes part in the collectives; rank 0 reports) ---------------
     extras = {}
@@ -361,7 +365,7 @@ def main():
                                    "params, seeded random weights" % T,
                        "candidates_per_gpu_per_step": args.candidates, "internal_batch": args.batch,
                        "gflop_per_candidate": round(fl["total"] / 1e9, 2), "parallelism": f"candidate-shard x{world}"},
-            "effective_tflops": round(value * fl["total"] / 1e12, 2),
+            "effective_tflops": round(value * fl["total"] / 1e12, 2), "f16x3_overflow_count": overflow,
             "roofline": roof, "cpu_baseline": cpu, "refstyle_gpu": refstyle,
             "vs_refstyle_gpu": (round(value / refstyle["value"], 2) if refstyle else None),
             "extras": extras or None, "e2e_latency": e2e,

@@ -288,6 +288,14 @@ int asw_convgemm_f32(const asw_convgemm_args* args, void* stream);
  * power-of-two pre-scale that keeps the lo parts out of the fp16 subnormal range; returns
  * the shift through *w_shift.  hi/lo: n uint16 each (host). */
 int asw_split_weights_f16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, int32_t* w_shift);
+/* f16x3 range guard: activations are split to fp16 halves (saturating at +-65504) when a GEMM
+ * stages them.  Normalised tensors are bounded; the un-normalised ones (outputs of epilogues
+ * without LayerNorm / GroupNorm statistics: masked latent, feed-forward intermediate, attention
+ * projections) are checked where they are produced.  Returns through *count how many threads
+ * of f16x3 launches on the current device wrote a value beyond the fp16 range (or a NaN) since
+ * the last reset; waits for the device.  Non-zero means a later GEMM clipped its input: rerun in
+ * precision 0.  The device must be the one the launches ran on. */
+int asw_f16x3_overflow_count(int reset, uint32_t* count);
 /* Number of stats partials per batch item the call above will write. */
 int asw_convgemm_stats_tiles(int M_out, int N);
 

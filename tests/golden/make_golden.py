@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Generate the golden vectors under tests/golden/ by running the REFERENCE's own
 code (imported read-only from /root/reference) on seeded inputs and weights.
 

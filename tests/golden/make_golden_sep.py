@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Golden vectors of the joint separation network (fixtures g11*) and of the evaluation
 matcher (g12), produced by running the REFERENCE's own code from /root/reference:
 

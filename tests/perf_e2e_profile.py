@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Diagnostic: cProfile of one JointModel.forward (host-side hot spots of the search)."""
 import cProfile
 import io

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Information only: how far apart two fp32 executions of the same network already are.
 Runs the oracle's torch.nn.functional statement of shift_and_sep with stock PyTorch-ROCm fp32
 ops on the MI355X and compares it with the reference's own CPU output (fixture g4b), next to the

@@ -1,6 +1,7 @@
-#!/usr/bin/env python3
 """Micro-benchmark of ONE layer through the C ABI (for rocprofv3 --pmc runs and A/B timing).
-Not a pytest module.  Usage: perf_kernel_micro.py <layer> [--reps N] [--batch B] [--precision f16x3|f32]
+Not a pytest module.  Usage: python3 tests/perf_kernel_micro.py <layer>  (under the profiler:
+`rocprofv3 --pmc ... -- python3 tests/perf_kernel_micro.py <layer>`, the interpreter itself after `--`)
+ [--reps N] [--batch B] [--precision f16x3|f32]
 layers: res64d1 res64d7 res64d49 res128d7 res256d7 res512d7 mask down0 qkv"""
 import argparse
 import math

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Information only (not a pytest module, not the product): times the REFERENCE-STYLE GPU
 path on the MI355X -- the oracle's torch.nn.functional statement of the spot network
 executed by stock PyTorch-ROCm ops (MIOpen / rocBLAS) under the reference's loop

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Diagnostic only: phase shares of the generic f16x3 GEMM main loop from an instrumented
 build (ASW_LIB_PATH=.abl/libasw_stamp.so).  Shares, not durations, are meaningful."""
 import ctypes

@@ -118,3 +118,28 @@ def test_shift_and_sep_full_f16x3_vs_reference_golden(golden):
     m.set_precision("f32")
     y32 = m.shift_and_sep(mix, list(g["offsets"]), Strict=1)
     assert min(snr_db(y32[i], g["y_strict1"][i]) for i in range(5)) > 100.0
+
+
+def test_f16x3_range_guard_counts_saturating_activations():
+    """The f16x3 mode splits activations to fp16 halves that saturate at +-65504.  The plain GEMM
+    epilogue counts un-normalised outputs beyond that range (asw_f16x3_overflow_count): zero for
+    the seeded network, non-zero once the mask path is scaled so that the latent exceeds it -- and
+    the exact-f32 mode of the same weights is not flagged."""
+    from acousticswarms_speech_amd import ops
+    from acousticswarms_speech_amd.config import SMALL
+    from acousticswarms_speech_amd.scenes import make_scene
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    mix = torch.from_numpy(make_scene(7, 2, 7, 4000).mix)
+    offs = [np.array([0, 0, 0, 0, 0, 0]), np.array([3, -5, 8, -13, 21, -34])]
+    sd = make_spot_state_dict(SMALL, seed=3)
+    ops.f16x3_overflow_count(reset=True)
+    SpotModel(SMALL, sd, batch_size=4, precision="f16x3").to("cuda").shift_and_sep(mix, offs, Strict=1)
+    assert ops.f16x3_overflow_count(reset=True) == 0
+    big = dict(sd)
+    big["mask_encoder.weight"] = sd["mask_encoder.weight"] * 3.0e3
+    big["reference_bypass.weight"] = sd["reference_bypass.weight"] * 3.0e3
+    SpotModel(SMALL, big, batch_size=4, precision="f32").to("cuda").shift_and_sep(mix, offs, Strict=1)
+    assert ops.f16x3_overflow_count(reset=True) == 0          # the exact mode has no such limit
+    SpotModel(SMALL, big, batch_size=4, precision="f16x3").to("cuda").shift_and_sep(mix, offs, Strict=1)
+    assert ops.f16x3_overflow_count(reset=True) > 0
