@@ -62,7 +62,9 @@ class SepModel:
                 raise RuntimeError(f"size mismatch for {k}: {tuple(clean[k].shape)} vs {tuple(shp)}")
         self._sd = clean
         if self._h is not None:
-            self._upload()
+            import torch
+            with torch.cuda.device(self.device):
+                self._upload()
         return self
 
     def _upload(self):

@@ -52,6 +52,7 @@ class SpotModel:
     # ---- weights -------------------------------------------------------------
     def load_state_dict(self, sd, strict: bool = True):
         """Reference-format state dict (numpy arrays or torch tensors)."""
+        import contextlib
         want = OrderedDict(spot_param_shapes(self.cfg))
         clean = OrderedDict()
         for k, v in sd.items():
@@ -66,7 +67,9 @@ class SpotModel:
                 raise RuntimeError(f"size mismatch for {k}: {tuple(clean[k].shape)} vs {tuple(shp)}")
         self._sd = clean
         if self._h is not None:
-            self._upload()
+            import torch
+            with (torch.cuda.device(self.device) if self.device is not None else contextlib.nullcontext()):
+                self._upload()
         return self
 
     def _upload(self):
@@ -87,21 +90,21 @@ class SpotModel:
             raise RuntimeError("no HIP device visible: the spot hot path has no CPU fallback")
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        torch.cuda.set_device(device)
         L = native.lib()
-        if self._h is not None:
-            L.asw_spot_destroy(self._h)
-            self._h = None
-        h = c_void_p()
-        cc = native.SpotConfigC.from_config(self.cfg)
-        native.check(L.asw_spot_create(byref(cc), byref(h)))
-        self._h = h
-        native.check(L.asw_spot_set_batch(self._h, int(self.batch_size)))
-        native.check(L.asw_spot_set_precision(self._h, self.PRECISIONS[self.precision]))
-        native.check(L.asw_spot_set_lanes(self._h, self.lanes))
-        self.device = device
-        if self._sd is not None:
-            self._upload()
+        with torch.cuda.device(device):            # the handle lives on this device; the process default is untouched
+            if self._h is not None:
+                L.asw_spot_destroy(self._h)
+                self._h = None
+            h = c_void_p()
+            cc = native.SpotConfigC.from_config(self.cfg)
+            native.check(L.asw_spot_create(byref(cc), byref(h)))
+            self._h = h
+            native.check(L.asw_spot_set_batch(self._h, int(self.batch_size)))
+            native.check(L.asw_spot_set_precision(self._h, self.PRECISIONS[self.precision]))
+            native.check(L.asw_spot_set_lanes(self._h, self.lanes))
+            self.device = device
+            if self._sd is not None:
+                self._upload()
         return self
 
     def eval(self):
@@ -265,6 +268,7 @@ class SpotModel:
         L = native.lib()
         native.check(L.asw_spot_get_tap(self._h, name.encode(), None, 0, byref(n), None))
         buf = torch.empty((n.value,), dtype=torch.float32, device=self.device)
-        native.check(L.asw_spot_get_tap(self._h, name.encode(), native.ptr(buf), n.value, byref(n),
-                                        native.current_stream()))
+        with torch.cuda.device(self.device):
+            native.check(L.asw_spot_get_tap(self._h, name.encode(), native.ptr(buf), n.value, byref(n),
+                                            native.current_stream()))
         return buf if shape is None else buf.view(*shape)

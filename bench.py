@@ -328,10 +328,21 @@ def main():
             ach = rec["work"] / (rec["ms"] * 1e-3) / 1e12
             tot_ms = sum(r["ms"] for r in prof.values())
             tot_work = sum(r["work"] for r in prof.values())
+            # HBM / fabric bytes per launch of the dominant kernel need separate rocprofv3 --pmc passes (the guide's
+            # recipe): taken OFFLINE over this very command and kept in profiles/r2/traffic.json.  Only quoted when
+            # the kernel and its per-launch batch are the ones of this run; otherwise null.
+            traffic = traffic_src = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r2", "traffic.json")))
+                if tj["kernel"] == name and tj["batch"] == min(args.batch, args.candidates) and T == 48000:
+                    traffic = int(tj["corrected_bytes_per_launch"])
+                    traffic_src = {"source": "offline: profiles/r2/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                             "`python bench.py`, same batch)", "algorithmic_bytes": int(tj["algorithmic_bytes"]),
+                                   "correction": tj["_correction"]}
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    # HBM bytes need separate rocprofv3 --pmc passes (profiles/r2/); nothing is measured in this run
-                    "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_detail": traffic_src,
                     "sustained_peak": ({"tflops": round(SUSTAINED_TFLOPS[args.precision], 1),
                                         "frac": round(ach / SUSTAINED_TFLOPS[args.precision], 4),
                                         "note": "MFMA-only loop on random operands, power-limited clock; "
