@@ -10,6 +10,8 @@
 // The bottleneck tensors are [S][L][d] fp32 channels-last with L = T/64 (750 at T = 48 000),
 // d = 512: a few MB, so every kernel here is one short pass and the stage is launch-latency
 // bound; the GEMMs between them run on the MFMA kernels of convgemm.hip.
+#include <cstdlib>
+
 #include "asw_common.h"
 
 namespace {
@@ -328,6 +330,168 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------
+// The same attention on the f32 matrix cores (head_dim 64, the full network's shape): exact fp32
+// arithmetic (v_mfma_f32_32x32x2_f32 is an fmaf chain), one workgroup (4 waves) per (sequence,
+// head, 64-query tile), online softmax over 64-key tiles.
+//   AC  = (Q+u) K^T            4 MFMA tiles (2 query x 2 key halves), one per wave
+//   BD: the relative-position term needs, for query i and key j of the tile, row (L-1)+j-i of P --
+//       127 consecutive rows per (query tile, key tile).  Wave (qi, kj) multiplies its 32 queries
+//       with the 64 P rows its block can touch (2 MFMA tiles), parks the 32 x 64 product in LDS
+//       and reads it back skewed: bd[i][j] = G[i][(j - i) + 31].
+//   O   = O * alpha + P V      wave (qi, dj) owns a 32 x 32 block of the 64 x 64 output tile.
+// ---------------------------------------------------------------------------------------
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int RM_BQ = 64, RM_BK = 64, RM_HD = 64, RM_LD = RM_HD + 4;     // row stride 68 floats: conflict-free b128 reads
+
+__device__ __forceinline__ floatx16 rm_mma(const float* a_row, const float* b_row, floatx16 acc) {
+  // a_row / b_row include this lane's (row, 4*(lane>>5)) offset; 8 k per iteration, hd = 64
+#pragma unroll
+  for (int kk = 0; kk < RM_HD / 8; ++kk) {
+    const float4 a = *reinterpret_cast<const float4*>(a_row + kk * 8);
+    const float4 b = *reinterpret_cast<const float4*>(b_row + kk * 8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                                    const float* __restrict__ bu, const float* __restrict__ bv,
+                                                                    int L, int d, float scale, float* __restrict__ ctx) {
+  extern __shared__ __align__(16) float smem[];
+  float* Qu = smem;                          // [64][68]
+  float* Qv = Qu + RM_BQ * RM_LD;            // [64][68]
+  float* KV = Qv + RM_BQ * RM_LD;            // [64][68] K tile, then V tile
+  float* Pw = KV + RM_BK * RM_LD;            // [128][68] window of P rows; later 4 x [32][68] skew buffers
+  float* Sc = Pw + 2 * RM_BK * RM_LD;        // [64][68] scores, then probabilities
+  float* rm = Sc + RM_BQ * RM_LD;            // [64] running max
+  float* rl = rm + RM_BQ;                    // [64] running sum
+  float* ra = rl + RM_BQ;                    // [64] rescale factor of this step
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RM_BQ;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int qi = wid >> 1, kj = wid & 1;
+  const float* base = qkv + (long)b * L * 3 * d;
+
+  for (int i = tid; i < RM_BQ * (RM_HD / 4); i += 256) {
+    const int r = i / (RM_HD / 4), c4 = (i - r * (RM_HD / 4)) * 4;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + r < L) q = *reinterpret_cast<const float4*>(base + (long)(q0 + r) * 3 * d + h * RM_HD + c4);
+    const float4 u = *reinterpret_cast<const float4*>(bu + h * RM_HD + c4);
+    const float4 v = *reinterpret_cast<const float4*>(bv + h * RM_HD + c4);
+    *reinterpret_cast<float4*>(Qu + r * RM_LD + c4) = make_float4((q.x + u.x) * scale, (q.y + u.y) * scale, (q.z + u.z) * scale, (q.w + u.w) * scale);
+    *reinterpret_cast<float4*>(Qv + r * RM_LD + c4) = make_float4((q.x + v.x) * scale, (q.y + v.y) * scale, (q.z + v.z) * scale, (q.w + v.w) * scale);
+  }
+  if (tid < RM_BQ) { rm[tid] = -INFINITY; rl[tid] = 0.f; }
+  floatx16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float* G = Pw + wid * 32 * RM_LD;          // this wave's skew buffer (aliases the P window once it is consumed)
+  const int rt0 = kj - qi + 1;               // first of the two 32-row blocks of the P window this wave needs
+
+  for (int k0 = 0; k0 < L; k0 += RM_BK) {
+    __syncthreads();                         // previous step fully consumed (also covers Qu / Qv / rm / rl)
+    for (int i = tid; i < RM_BK * (RM_HD / 4); i += 256) {
+      const int r = i / (RM_HD / 4), c4 = (i - r * (RM_HD / 4)) * 4;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + r < L) kv = *reinterpret_cast<const float4*>(base + (long)(k0 + r) * 3 * d + d + h * RM_HD + c4);
+      *reinterpret_cast<float4*>(KV + r * RM_LD + c4) = kv;
+    }
+    const int pbase = (L - 1) + k0 - q0 - (RM_BQ - 1);
+    for (int i = tid; i < 2 * RM_BK * (RM_HD / 4); i += 256) {
+      const int r = i / (RM_HD / 4), c4 = (i - r * (RM_HD / 4)) * 4;
+      const int m = pbase + r;
+      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m >= 0 && m <= 2 * L - 2) pv = *reinterpret_cast<const float4*>(P + (long)m * d + h * RM_HD + c4);
+      *reinterpret_cast<float4*>(Pw + r * RM_LD + c4) = pv;
+    }
+    __syncthreads();
+    floatx16 ac, g0, g1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ac[r] = 0.f; g0[r] = 0.f; g1[r] = 0.f; }
+    const float* qa = Qu + (qi * 32 + lr) * RM_LD + lh * 4;
+    const float* qb = Qv + (qi * 32 + lr) * RM_LD + lh * 4;
+    ac = rm_mma(qa, KV + (kj * 32 + lr) * RM_LD + lh * 4, ac);
+    g0 = rm_mma(qb, Pw + (rt0 * 32 + lr) * RM_LD + lh * 4, g0);
+    g1 = rm_mma(qb, Pw + ((rt0 + 1) * 32 + lr) * RM_LD + lh * 4, g1);
+    __syncthreads();                         // every wave is done with the P window and the K tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      G[row * RM_LD + lr] = g0[r];
+      G[row * RM_LD + 32 + lr] = g1[r];
+    }
+    // V tile (the K tile is consumed) while the skew buffers settle
+    for (int i = tid; i < RM_BK * (RM_HD / 4); i += 256) {
+      const int r = i / (RM_HD / 4), c4 = (i - r * (RM_HD / 4)) * 4;
+      float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + r < L) vv = *reinterpret_cast<const float4*>(base + (long)(k0 + r) * 3 * d + 2 * d + h * RM_HD + c4);
+      *reinterpret_cast<float4*>(KV + r * RM_LD + c4) = vv;
+    }
+    __syncthreads();
+    {
+      const bool valid = k0 + kj * 32 + lr < L;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float s = ac[r] + G[row * RM_LD + (lr - row + 31)];            // bd[i][j] = G[i][(j - i) + 31]
+        Sc[(qi * 32 + row) * RM_LD + kj * 32 + lr] = valid ? s : -INFINITY;
+      }
+    }
+    __syncthreads();
+    {                                        // online softmax: 4 lanes per query row
+      const int row = tid >> 2, sub = tid & 3;
+      float* pr = Sc + row * RM_LD;
+      float m = -INFINITY;
+      for (int j = sub; j < RM_BK; j += 4) m = fmaxf(m, pr[j]);
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
+      const float m_old = rm[row], m_new = fmaxf(m_old, m);
+      float sum = 0.f;
+      for (int j = sub; j < RM_BK; j += 4) {
+        const float e = expf(pr[j] - m_new);                                 // exp(-inf) = 0 for padded keys
+        pr[j] = e;
+        sum += e;
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      if (sub == 0) {
+        const float alpha = expf(m_old - m_new);                             // 0 on the first step (m_old = -inf)
+        ra[row] = alpha;
+        rl[row] = rl[row] * alpha + sum;
+        rm[row] = m_new;
+      }
+    }
+    __syncthreads();
+    {                                        // O = O * alpha + P V : wave (qi, dj = kj) owns a 32 x 32 block
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= ra[qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      const float* pa = Sc + (qi * 32 + lr) * RM_LD + lh * 4;
+      const float* vb = KV + (lh * 4) * RM_LD + kj * 32 + lr;
+#pragma unroll 4
+      for (int kk = 0; kk < RM_BK / 8; ++kk) {
+        const float4 a = *reinterpret_cast<const float4*>(pa + kk * 8);
+        const float b0 = vb[(kk * 8 + 0) * RM_LD], b1 = vb[(kk * 8 + 1) * RM_LD], b2 = vb[(kk * 8 + 2) * RM_LD],
+                    b3 = vb[(kk * 8 + 3) * RM_LD];
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, o, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int q = q0 + row;
+    if (q < L) ctx[((long)b * L + q) * d + h * RM_HD + kj * 32 + lr] = o[r] / rl[row];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Inter-speaker attention: at every (item n, time step t, head h) the S speakers are the
 // sequence (nn.MultiheadAttention inside nn.TransformerEncoderLayer(batch_first), applied to
 // x.reshape(N*T, S, F), SpeakerSeparation/network.py:311-316).  qkv [N][S][L][3d] standard
@@ -471,6 +635,17 @@ extern "C" int asw_relpos_attention(const float* qkv, const float* P, const floa
   ASW_CHECK_ARG(qkv && P && bias_u && bias_v && ctx, "relpos_attention: null pointer");
   ASW_CHECK_ARG(BS > 0 && BS <= 65535 && L > 0 && nhead > 0 && nhead <= 65535 && d % nhead == 0, "relpos_attention: bad shape");
   hipStream_t s = asw::as_stream(stream);
+  static const bool valu_only = getenv("ASW_RELPOS_VALU") != nullptr;          // A/B switch for measurements
+  if (d / nhead == RM_HD && d % 4 == 0 && !valu_only) {
+    constexpr size_t smem = sizeof(float) * ((size_t)(3 * RM_BQ + 2 * RM_BK + RM_BQ) * RM_LD + 3 * RM_BQ);
+    static asw::SmemAttr attr;                                 // per device
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(relpos_attention_mfma_kernel), smem)) return rc;
+    dim3 grid(asw::cdiv(L, RM_BQ), nhead, BS);
+    asw::ProfScope prof(s, "relpos_attention_mfma", 6.0 * BS * nhead * (double)L * L * RM_HD);
+    hipLaunchKernelGGL(relpos_attention_mfma_kernel, grid, dim3(256), smem, s, qkv, P, bias_u, bias_v, L, d, scale, ctx);
+    ASW_LAUNCH_CHECK();
+    return ASW_OK;
+  }
   switch (d / nhead) {
     case 16: return launch_relpos<16>(qkv, P, bias_u, bias_v, BS, L, d, nhead, scale, ctx, s);
     case 32: return launch_relpos<32>(qkv, P, bias_u, bias_v, BS, L, d, nhead, scale, ctx, s);

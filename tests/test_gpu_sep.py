@@ -86,7 +86,7 @@ def test_glu_and_dwconv(ops):
         assert _relerr(got.cpu(), want) < 2e-6
 
 
-@pytest.mark.parametrize("L,d,H", [(75, 128, 8), (200, 256, 8), (130, 512, 8)])
+@pytest.mark.parametrize("L,d,H", [(75, 128, 8), (200, 256, 8), (130, 512, 8), (64, 512, 8), (750, 512, 8)])
 def test_relpos_attention(ops, L, d, H):
     """RelPosMHAXL core against the pad-and-reshape rel_shift statement."""
     B, hd = 2, d // H
