@@ -34,6 +34,7 @@ class JointModel(object):
         self.times = [0, 0, 0, 0, 0]
         self.previous_config = None
         self.Mic_processor = None
+        self._mix_dev = None
 
     def setup(self, mic_positions, speaker_range, cached=False, cached_folder=None):
         """(Re)build the geometry tables unless the configuration is unchanged (:125-137).
@@ -43,8 +44,17 @@ class JointModel(object):
         if key == self.previous_config:
             print("reuse the previous recycle!")
             return
+        import gc
+        gc.unfreeze()                       # a previous geometry may go now
         self.Mic_processor = MicArray(mic_positions, Spk_Range=speaker_range, device=self.device)
         self.previous_config = key
+        # The geometry tables are tens of thousands of small arrays and lists that live as long as
+        # this configuration.  Left in the collector's oldest generation they make every full
+        # collection of the interpreter a 50 ms pause that lands at random inside a forward()
+        # (measured: 22-66 ms on the first statement after the search).  Move them to the permanent
+        # generation: later collections only look at what a forward() itself allocates.
+        gc.collect()
+        gc.freeze()
 
     def forward(self, mix_data):
         """-> (patches, audio_loc, audio, SRP_drop, stage1_drop, spot_times) (:142-149)."""
@@ -72,7 +82,18 @@ class JointModel(object):
         assert self.previous_config is not None, \
             "Microphone positions and spk range were not provided, did you forget to call .setup()?"
         mp = self.Mic_processor
-        patch_list, _ = self._timed(0, mp.Apply_SRP_PHAT, mix_data)
+        # One upload of the mixture per forward, inside the first timed stage: the HIP models take
+        # the resident copy (a host tensor would be copied again by every stage -- and a pageable
+        # H2D right after the fine stage was measured at 29 ms for these 1.3 MB).  Any other
+        # duck-typed model keeps receiving the caller's tensor.
+        self._mix_dev = None
+
+        def srp_stage(m):
+            self._mix_dev = self._resident(m)
+            return mp.Apply_SRP_PHAT(m)
+        patch_list, _ = self._timed(0, srp_stage, mix_data)
+        if self._takes_resident(self.spot_model) and self._mix_dev is not None:
+            mix_data = self._mix_dev
         if len(patch_list) <= 0:
             print("No spk picked in SRP-PHAT")
             return [], [], 0, 0, 0
@@ -90,9 +111,25 @@ class JointModel(object):
             return [], [], 0, 0, 0
         return patch_final, np.array(audio_final), 0, 0, spot_times
 
+    @staticmethod
+    def _takes_resident(model):
+        """HIP models of this package (SpotModel / SepModel) accept a device-resident mixture."""
+        dev = getattr(model, "device", None)
+        return getattr(dev, "type", None) == "cuda" and (hasattr(model, "shift_and_sep_device") or hasattr(model, "infer_device"))
+
+    def _resident(self, mix_data):
+        for m in (self.spot_model, self.sep_model):
+            if m is not None and self._takes_resident(m):
+                import torch
+                return torch.as_tensor(mix_data).to(m.device, dtype=torch.float32).contiguous()
+        return None
+
     def separate_by_localization(self, mix_data, target_patches):
         if len(target_patches) == 0 or self.sep_model is None:
             return None
+        if self._takes_resident(self.sep_model) and getattr(self, "_mix_dev", None) is not None \
+                and tuple(self._mix_dev.shape) == tuple(mix_data.shape):
+            mix_data = self._mix_dev
         return self.sep_model.infer(mix_data, [p[0] for p in target_patches])
 
     def to(self, device=None):

@@ -133,21 +133,28 @@ def e2e_latency(model, sep_model, scene, dev):
         t0 = time.perf_counter()
         jm.setup(scene.mic_positions, scene.speaker_range)
         setup_s = time.perf_counter() - t0
-        jm.forward(mix)                                   # warm-up (workspace growth, gate cache)
-        out = jm.forward(mix)
+        for _ in range(3):                                # warm-up: workspace growth, gate cache, torch's
+            jm.forward(mix)                               # caching allocator reaching its steady state
+        runs = []
+        for _ in range(3):
+            out = jm.forward(mix)
+            runs.append(list(jm.times))
+    runs.sort(key=sum)
+    times = runs[1]                                       # the median forward of three
     mp = jm.Mic_processor
     names = ["srp_phat", "coarse", "fine", "clustering", "joint_sep"]
-    stages = {k: round(v * 1e3, 2) for k, v in zip(names, jm.times)}
-    rec = {"unit": "ms", "stages": stages,
+    stages = {k: round(v * 1e3, 2) for k, v in zip(names, times)}
+    rec = {"unit": "ms", "stages": stages, "protocol": "3 warm-up forwards, median (by total) of 3 measured forwards",
+           "totals_of_the_three_runs": [round(sum(r) * 1e3, 2) for r in runs],
            "spot_calls": {"coarse": int(mp.big_spotforming_times), "fine": int(mp.spotforming_times)},
            "talkers_found": len(out[0]), "setup_excluded_s": round(setup_s, 2)}
     if sep_model is None:
         # no separation network behind sep_model: the figure is localisation only, stage 5 is not part of it
         del stages["joint_sep"]
-        rec["total_localize_only"] = round(sum(jm.times[:4]) * 1e3, 2)
+        rec["total_localize_only"] = round(sum(times[:4]) * 1e3, 2)
         rec["note"] = "localize-only latency (no joint separation network attached)"
     else:
-        rec["total"] = round(sum(jm.times) * 1e3, 2)
+        rec["total"] = round(sum(times) * 1e3, 2)
         rec["separated_rows"] = 0 if out[2] is None else int(out[2].shape[0])
     return rec
 

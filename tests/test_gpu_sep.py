@@ -259,3 +259,24 @@ def test_joint_model_runs_the_separation_stage():
     want = sep.infer(torch.from_numpy(sc.mix), [p[0] for p in patches])
     np.testing.assert_array_equal(audio, want)
     _log(f"joint model: {len(patches)} talkers, stage times {np.round(jm.times, 4)}")
+
+
+def test_infer_reference_native_length_property():
+    """T = 144 000 (3 s at the reference's native 48 kHz, bottleneck length 2250): the two
+    arithmetic modes of the FULL separation network agree to fp32-class accuracy and the f16x3
+    range guard stays silent."""
+    from acousticswarms_speech_amd import ops
+    from acousticswarms_speech_amd.config import SEP_FULL
+    from acousticswarms_speech_amd.scenes import make_scene
+    model, _sd = _model(SEP_FULL, 9, "f32")
+    sc = make_scene(1011, 2, 7, 144000)
+    mix = torch.from_numpy(sc.mix)
+    offs = list(sc.tdoa_samples())
+    y32 = model.infer_sample(mix, offs)
+    ops.f16x3_overflow_count(reset=True)
+    model.set_precision("f16x3")
+    y16 = model.infer_sample(mix, offs)
+    assert y32.shape == (2, 144000) and np.all(np.isfinite(y32))
+    snr = _snr(y16, y32)
+    _log(f"sep infer_sample FULL T=144000, 2 speakers: f16x3 vs f32 {snr:.1f} dB")
+    assert snr > 80.0 and ops.f16x3_overflow_count(reset=True) == 0
