@@ -736,7 +736,9 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
     case 128: return poly ? launch_res<128, 128, 2, 2, 4, 2>(a, s) : launch_res<128, 128, 2, 2, 1, 2>(a, s);
     case 256: return poly ? launch_res<64, 256, 1, 4, 2>(a, s) : launch_res<64, 256, 1, 4, 1>(a, s);
     case 512:
-      if (poly) return launch_res<64, 512, 1, 4, 2>(a, s);
+      // polyphase at C = 512 pays only for long phases: 45 rows per phase (T = 144 000) measured 243
+      // TFLOP/s against 307 for the contiguous halo image on the same layer shape at T = 48 000
+      if (poly && a.M_out / a.dil >= 64) return launch_res<64, 512, 1, 4, 2>(a, s);
       return a.dil >= 16 ? launch_res<64, 512, 1, 4, 1>(a, s) : launch_res<64, 512, 1, 4, 1, 2>(a, s);
     default: return 1;
   }
@@ -787,10 +789,15 @@ inline bool wide_tile(int N) { return N % 128 == 0; }
 // MAC but needs a grid of >= 2 workgroups per CU to stay balanced (measured: mask encoder
 // 242 -> 267 TFLOP/s, deep down/up convs 169 -> 201, but the 288-workgroup QKV GEMM is
 // faster on 128x128).
+// 3 = 192x256: the same 8-wave kernel with three MFMA row tiles per wave, for sequence lengths
+// that leave a 256-row tile a quarter or more empty (the bottleneck-side convolutions: 188 rows at
+// T = 48 000, 563 at T = 144 000 -> 2 % instead of 27 % of the MFMAs on padding rows).
 inline int wide_tile_kind(int B, int M_out, int N, int K) {
   if (M_out <= 128 || N % 256 != 0 || K < 256) return 0;
   const long blocks = (long)asw::cdiv(M_out, 256) * (N / 256) * B;
-  return blocks >= 512 ? 2 : 0;
+  if (blocks < 512) return 0;
+  const long pad256 = (long)asw::cdiv(M_out, 256) * 256, pad192 = (long)asw::cdiv(M_out, 192) * 192;
+  return pad192 * 10 <= pad256 * 9 ? 3 : 2;                  // at least 10 % fewer padded rows
 }
 
 }  // namespace
@@ -909,6 +916,12 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
       // f16x3 is bound by the bytes each CU can pull per cycle, so take the largest tile the
       // shape fills: 256x256 (8 waves, 1/32 B per MAC), 256x128, else 128x128 (1/16 B per MAC)
       const int t = wide_tile_kind(a.B, a.M_out, a.N, a.taps * a.Cin);
+      if (t == 3) {
+        if (a.mul) return launch<192, 256, 32, 2, 4, false, false, true, true>(a, s);
+        if (stats && a.A2) return launch<192, 256, 32, 2, 4, false, true, false, true, true>(a, s);
+        return stats ? launch<192, 256, 32, 2, 4, false, true, false, true>(a, s)
+                     : launch<192, 256, 32, 2, 4, false, false, false, true>(a, s);
+      }
       if (t == 2) {
         if (a.mul) return launch<256, 256, 32, 2, 4, false, false, true, true>(a, s);
         if (stats && a.A2) return launch<256, 256, 32, 2, 4, false, true, false, true, true>(a, s);

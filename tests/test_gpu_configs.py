@@ -234,3 +234,23 @@ def test_f16x3_flip_rate_full_size(full_weights):
     assert tot["final"] == 0 and tot["coarse"] == 0
     assert rec["flip_rate_per_candidate"] <= 1e-3
     assert worst_cm <= 2.0
+
+
+# ------------------------------------------------------------------------------ real multi-GPU
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X on one node (RCCL over xGMI)")
+def test_bench_two_ranks_over_rccl():
+    """`bench.py --gpus 2` on real hardware: two ranks, one GPU each, nccl (= RCCL) backend, the
+    energy all-gather of every step over xGMI.  Skipped on the one-GPU boxes this suite normally
+    runs on; it is the test to run whenever a multi-GPU lease exists."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-e2e", "--no-extras", "--cpu-sample", "0", "--candidates", "64", "--batch", "64"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "candidate-shard x2"
