@@ -536,19 +536,19 @@ __global__ __launch_bounds__(64 * WM * WN) void convgemm16_kernel(const asw_conv
 // its B operand with one coalesced 1 KiB load per fragment, one k-step ahead of the MFMAs
 // (they are L2/L1-resident: a layer's weights are at most 7.3 MB and shared by every
 // workgroup).  No barrier inside the taps x k-steps of a slice.
-template <int BM, int PH>
+template <int BM, int PH, bool POLY>
 struct ResRows {
   static constexpr int BMJ = BM / PH;
-  int m0, jb, pb, dil, T;                    // PH == 1 uses m0; PH > 1 uses (jb, pb)
+  int m0, jb, pb, dil, T;                    // contiguous tiles use m0; polyphase tiles (jb, pb)
   __device__ __forceinline__ int operator()(int trow) const {
-    if (PH == 1) { const int t = m0 + trow; return t < T ? t : -1; }
+    if (!POLY) { const int t = m0 + trow; return t < T ? t : -1; }
     const int ph = pb * PH + trow / BMJ;
     const int t = dil * (jb * BMJ + trow % BMJ) + ph;
     return (ph < dil && t < T) ? t : -1;
   }
 };
 
-template <int BM, int C, int WM, int WN, int PH, int QD = 4>
+template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1)>
 __global__ __launch_bounds__(64 * WM * WN)
 __attribute__((amdgpu_waves_per_eu(WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 ? 2 : 3) : 1))))
 void resconv16_kernel(const asw_convgemm_args p) {
@@ -569,13 +569,13 @@ void resconv16_kernel(const asw_convgemm_args p) {
   const int b = blockIdx.z;
   const int taps = p.taps, dil = p.dil, pad = p.pad;
   const int T = p.M_out;
-  // PH == 1: blockIdx.x = row tile.  PH > 1: blockIdx.x = jb * n_pb + pb.
+  // contiguous: blockIdx.x = row tile.  polyphase: blockIdx.x = jb * n_pb + pb (PH phases per workgroup).
   const int n_pb = (dil + PH - 1) / PH;
-  const int jb = PH == 1 ? 0 : blockIdx.x / n_pb, pb = PH == 1 ? 0 : blockIdx.x % n_pb;
+  const int jb = !POLY ? 0 : blockIdx.x / n_pb, pb = !POLY ? 0 : blockIdx.x % n_pb;
   const int m0 = blockIdx.x * BM;
-  const int RJ = BMJ + (PH == 1 ? (taps - 1) * dil : taps - 1);   // image rows per phase
+  const int RJ = BMJ + (!POLY ? (taps - 1) * dil : taps - 1);      // image rows per phase
   const int R = PH * RJ;
-  const int tapstep = PH == 1 ? dil : 1;
+  const int tapstep = !POLY ? dil : 1;
   const __amdgpu_buffer_rsrc_t rX = act_rsrc(p.A + (long)b * p.a_batch_stride, (long)T * C);
   const half8* __restrict__ Wh = reinterpret_cast<const half8*>(p.Wf_hi);
   const half8* __restrict__ Wl = reinterpret_cast<const half8*>(p.Wf_lo);
@@ -607,7 +607,7 @@ void resconv16_kernel(const asw_convgemm_args p) {
         const int row = r0 + u * SROWS + srow;
         int g;
         bool ok = row < R;
-        if (PH == 1) {
+        if (!POLY) {
           g = m0 - pad + row;
         } else {
           const int ph = pb * PH + row / RJ;
@@ -673,25 +673,25 @@ void resconv16_kernel(const asw_convgemm_args p) {
     }
   }
   epilogue<BM, C, WM, WN, true, false, true, false>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
-                                       ResRows<BM, PH>{m0, jb, pb, dil, T}, blockIdx, gridDim.y);
+                                       ResRows<BM, PH, POLY>{m0, jb, pb, dil, T}, blockIdx, gridDim.y);
 }
 
-template <int BM, int C, int WM, int WN, int PH, int QD = 4>
+template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1)>
 int launch_res(const asw_convgemm_args& a, hipStream_t s) {
   constexpr int BMJ = BM / PH;
-  const int RJ = BMJ + (PH == 1 ? (a.taps - 1) * a.dil : a.taps - 1);
+  const int RJ = BMJ + (!POLY ? (a.taps - 1) * a.dil : a.taps - 1);
   const size_t img = (size_t)PH * RJ * 272;
   const size_t slab = (size_t)(WM * 32) * (C + 4) * sizeof(float);
   const size_t smem = img > slab ? img : slab;
   if (smem > 160 * 1024) return 1;                     // caller falls back to the generic kernel
-  auto kern = resconv16_kernel<BM, C, WM, WN, PH, QD>;
+  auto kern = resconv16_kernel<BM, C, WM, WN, PH, QD, POLY>;
   static asw::SmemAttr attr;                            // per device
   if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
-  const int gx = PH == 1 ? asw::cdiv(a.M_out, BM)
-                         : asw::cdiv(asw::cdiv(a.M_out, a.dil), BMJ) * asw::cdiv(a.dil, PH);
+  const int gx = !POLY ? asw::cdiv(a.M_out, BM)
+                       : asw::cdiv(asw::cdiv(a.M_out, a.dil), BMJ) * asw::cdiv(a.dil, PH);
   dim3 grid(gx, 1, a.B);
   char nm[96];
-  int nl = snprintf(nm, sizeof nm, "resconv16<%d,%d,ph%d%s>", BM, C, PH, QD == 2 ? ",q2" : "");
+  int nl = snprintf(nm, sizeof nm, "resconv16<%d,%d,%s%d%s>", BM, C, POLY ? "poly" : "ph", PH, QD == 2 ? ",q2" : "");
   if (asw::prof_detail()) snprintf(nm + nl, sizeof nm - nl, "[B%d M%d N%d K%d d%d]", a.B, a.M_out, a.N, a.taps * a.Cin, a.dil);
   asw::ProfScope prof(s, nm, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, a);
@@ -711,7 +711,8 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
   // large dilation: polyphase row sets -- but only while every phase still fills a 32-row
   // MFMA tile; on short sequences (T/dil < 32, e.g. T = 752 at dil 49) most of each tile
   // would be empty (measured: 141 vs 243 TFLOP/s), so those stay contiguous
-  const bool poly = a.dil >= 16 && a.M_out / a.dil >= 32;
+  const int rows_per_phase = a.M_out / a.dil;
+  const bool poly = a.dil >= 16 && rows_per_phase >= 32;
   // Tile / prefetch choices are measured (tests/perf_layers.py, T = 48 000, batch 64):
   //  C = 64  : waves 2x2 (64 rows x 32 columns each) halves the weight fragments every wave
   //            pulls through L1 compared with 4x1 -> 222 -> 257 TFLOP/s.  (A persistent variant
@@ -727,13 +728,20 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
   // workgroup.  With the epilogue removed the same loops run at 355-385 TFLOP/s, the level of an
   // idealised k-step loop fed from L2 on random data (tests/micro/cu_probe.hip: 400).
   switch (a.N) {
-    case 64: {
-      static const int v64 = getenv("ASW_RES64") ? atoi(getenv("ASW_RES64")) : 0;     // experiment switch
-      if (v64 == 1) return poly ? launch_res<256, 64, 4, 1, 4>(a, s) : launch_res<256, 64, 4, 1, 1>(a, s);
-      if (v64 == 2) return poly ? launch_res<256, 64, 2, 1, 4>(a, s) : launch_res<256, 64, 2, 1, 1>(a, s);
-      return poly ? launch_res<128, 64, 2, 2, 4>(a, s) : launch_res<128, 64, 2, 2, 1>(a, s);
-    }
-    case 128: return poly ? launch_res<128, 128, 2, 2, 4, 2>(a, s) : launch_res<128, 128, 2, 2, 1, 2>(a, s);
+    // Dilation 49 as polyphase dilation-1 convolutions, PH phases per workgroup (measured at
+    // T = 48 000, batch 64, TFLOP/s for PH = 1 / 2 / 4): C = 64: 243 / 238 / 205; C = 128: 292 / 307 /
+    // 282; C = 256: 300 / 301 / -.  Fewer phases per workgroup mean fewer halo rows in the image
+    // (134 / 140 / 152 rows for 128 outputs) and longer runs of one phase -- as long as a phase
+    // (M_out / dil rows) still fills the BM / PH rows the workgroup gives it.
+    // Round 2 also measured, for C = 64: 256-row tiles with 4 x 1 waves (221 vs 262 TFLOP/s at
+    // dilation 1) and 2 waves of 128 x 64 (155): the layer is latency bound, fewer resident waves lose.
+    case 64:
+      if (!poly) return launch_res<128, 64, 2, 2, 1>(a, s);
+      if (rows_per_phase >= 96) return launch_res<128, 64, 2, 2, 1, 4, true>(a, s);
+      return rows_per_phase >= 48 ? launch_res<128, 64, 2, 2, 2>(a, s) : launch_res<128, 64, 2, 2, 4>(a, s);
+    case 128:
+      if (!poly) return launch_res<128, 128, 2, 2, 1, 2>(a, s);
+      return rows_per_phase >= 48 ? launch_res<128, 128, 2, 2, 2, 2>(a, s) : launch_res<128, 128, 2, 2, 4, 2>(a, s);
     case 256: return poly ? launch_res<64, 256, 1, 4, 2>(a, s) : launch_res<64, 256, 1, 4, 1>(a, s);
     case 512:
       // polyphase at C = 512 pays only for long phases: 45 rows per phase (T = 144 000) measured 243
