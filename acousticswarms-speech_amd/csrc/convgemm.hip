@@ -736,6 +736,9 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
     // Round 2 also measured, for C = 64: 256-row tiles with 4 x 1 waves (221 vs 262 TFLOP/s at
     // dilation 1) and 2 waves of 128 x 64 (155): the layer is latency bound, fewer resident waves lose.
     case 64:
+      // at C = 64 even dilation 7 is better off as 7 single-phase tiles (halo 6 instead of 42 rows per
+      // 128 outputs, image 36 instead of 46 KB -> 4 resident workgroups): 238 -> 257 TFLOP/s
+      if (a.dil >= 7 && a.dil < 16 && rows_per_phase >= 96) return launch_res<128, 64, 2, 2, 1, 4, true>(a, s);
       if (!poly) return launch_res<128, 64, 2, 2, 1>(a, s);
       if (rows_per_phase >= 96) return launch_res<128, 64, 2, 2, 1, 4, true>(a, s);
       return rows_per_phase >= 48 ? launch_res<128, 64, 2, 2, 2>(a, s) : launch_res<128, 64, 2, 2, 4>(a, s);
