@@ -67,10 +67,22 @@ struct RowsContig {
   __device__ __forceinline__ int operator()(int trow) const { const int t = m0 + trow; return t < M ? t : -1; }
 };
 
-template <int BM, int BN, int WM, int WN, bool LN, bool STATS, bool RESID, bool MUL, typename RowMap>
+// Row-phase geometry of the epilogue: a row is BN/4 float4; LPR lanes share a row (RPI rows per
+// wave instruction, VPL float4 per lane); each wave walks its share of a WM*32-row slab in NSTEP steps.
+template <int BN, int WM, int WN>
+struct EpiGeom {
+  static constexpr int NW = WM * WN;
+  static constexpr int LPR = (BN / 4 < 64) ? BN / 4 : 64;
+  static constexpr int RPI = 64 / LPR;
+  static constexpr int VPL = BN / 4 / LPR;
+  static constexpr int NSTEP = WM * 32 / (NW * RPI);
+};
+
+template <int BM, int BN, int WM, int WN, bool LN, bool STATS, bool RESID, bool MUL, typename RowMap, bool RESPRE = false>
 __device__ __forceinline__ void epilogue(  // WM*WN waves (4 or 8)
 floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
-                                         float* smem, float acc_scale, const RowMap& rowmap, const dim3 tile, const int ncol) {
+                                         float* smem, float acc_scale, const RowMap& rowmap, const dim3 tile, const int ncol,
+                                         const float4* rpre = nullptr) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDC = BN + 4;
   float* Ct = smem;
@@ -102,11 +114,9 @@ floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
     // instruction, VPL float4 per lane), so each wave walks its 8*WM slab rows in 8 steps.
     // Steps are processed four at a time with every global load (residual / gate tensor)
     // issued before the first use: the loads of four steps overlap instead of serialising.
-    constexpr int NW = WM * WN;
-    constexpr int LPR = (BN / 4 < 64) ? BN / 4 : 64;
-    constexpr int RPI = 64 / LPR;
-    constexpr int VPL = BN / 4 / LPR;
-    constexpr int NSTEP = WM * 32 / (NW * RPI);        // steps each wave needs for its slab rows
+    using G = EpiGeom<BN, WM, WN>;
+    constexpr int NW = G::NW, LPR = G::LPR, RPI = G::RPI, VPL = G::VPL;
+    constexpr int NSTEP = G::NSTEP;                    // steps each wave needs for its slab rows
     constexpr int UNR = NSTEP < 4 ? NSTEP : 4;
     static_assert(NSTEP >= 1 && NSTEP % UNR == 0 && WM * 32 == NSTEP * NW * RPI, "slab rows must split evenly");
     const int sub = lane / LPR, lc = lane % LPR;
@@ -127,7 +137,8 @@ floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
 #pragma unroll
         for (int q = 0; q < VPL; ++q) {
           const int col = (lc + q * LPR) * 4;
-          if (RESID) v[u][q] = *reinterpret_cast<const float4*>(p.resid + obase[u] + col);
+          if (RESID && RESPRE) v[u][q] = rpre[(tm * NSTEP + it0 + u) * VPL + q];     // residual taken from the LDS image
+          else if (RESID) v[u][q] = *reinterpret_cast<const float4*>(p.resid + obase[u] + col);
           if (MUL) v[u][q] = *reinterpret_cast<const float4*>(p.mul + obase[u] + col);
         }
       }
@@ -536,6 +547,18 @@ __global__ __launch_bounds__(64 * WM * WN) void convgemm16_kernel(const asw_conv
 // its B operand with one coalesced 1 KiB load per fragment, one k-step ahead of the MFMAs
 // (they are L2/L1-resident: a layer's weights are at most 7.3 MB and shared by every
 // workgroup).  No barrier inside the taps x k-steps of a slice.
+#ifdef ASW_PHASE_TIMING
+// Diagnostic build only (tests/micro/phase_timing.md): cycles wave 0 of every workgroup spends in
+// each phase of a residual-layer tile, summed over workgroups.  [0] staging (global loads, split,
+// LDS writes, barrier), [1] taps x k-steps, [2] epilogue, [3] workgroups counted.
+__device__ unsigned long long g_phase_cycles[4] = {0, 0, 0, 0};
+#define ASW_PHASE_MARK(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define ASW_PHASE_MARK(var)
+#endif
+#ifndef ASW_RES128_WAVES
+#define ASW_RES128_WAVES 3
+#endif
 template <int BM, int PH, bool POLY>
 struct ResRows {
   static constexpr int BMJ = BM / PH;
@@ -550,7 +573,7 @@ struct ResRows {
 
 template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1)>
 __global__ __launch_bounds__(64 * WM * WN)
-__attribute__((amdgpu_waves_per_eu(WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 ? 2 : 3) : 1))))
+__attribute__((amdgpu_waves_per_eu(C == 64 ? 4 : WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 ? 2 : (C == 128 ? ASW_RES128_WAVES : 3)) : (C == 64 && WM * WN == 4 ? 4 : 1)))))
 void resconv16_kernel(const asw_convgemm_args p) {
   static_assert(QD == 2 || QD == 4, "B prefetch depth in k-steps");
   static_assert(WM * WN == 2 || WM * WN == 4 || WM * WN == 8, "2, 4 or 8 waves per workgroup");
@@ -597,7 +620,12 @@ void resconv16_kernel(const asw_convgemm_args p) {
   }
   const int nt0 = wn * TN;                            // first N fragment of this wave
 
+  ASW_PHASE_MARK(t_begin);
+#ifdef ASW_PHASE_TIMING
+  unsigned long long t_stage = 0, t_loop = 0;
+#endif
   for (int cc = 0; cc < C / 64; ++cc) {
+    ASW_PHASE_MARK(t_s0);
     __syncthreads();                                   // previous slice fully consumed
     // ---- stage + split the image of this channel slice (8 rows per thread in flight)
     for (int r0 = 0; r0 < R; r0 += SROWS * 8) {
@@ -661,6 +689,7 @@ void resconv16_kernel(const asw_convgemm_args p) {
     // before its use -- enough to cover an L2 hit without the register cost of a second
     // whole-tap set (which halves occupancy; measured slower for C <= 128).
     half8 qh[QD][TN], ql[QD][TN];
+    ASW_PHASE_MARK(t_s1);
 #pragma unroll
     for (int ks = 0; ks < QD; ++ks) bload(0, ks, qh[ks], ql[ks]);
     for (int tap = 0; tap < taps; ++tap) {
@@ -671,9 +700,61 @@ void resconv16_kernel(const asw_convgemm_args p) {
         if (ntap < taps) bload(ntap, nk % 4, qh[ks % QD], ql[ks % QD]);
       }
     }
+#ifdef ASW_PHASE_TIMING
+    {
+      // make the timestamp wait for the MFMAs: read one accumulator lane
+      float sink = acc[0][0][0];
+      asm volatile("" ::"v"(sink));
+      const unsigned long long t_s2 = __builtin_readcyclecounter();
+      t_stage += t_s1 - t_s0;
+      t_loop += t_s2 - t_s1;
+    }
+#endif
   }
-  epilogue<BM, C, WM, WN, true, false, true, false>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
-                                       ResRows<BM, PH, POLY>{m0, jb, pb, dil, T}, blockIdx, gridDim.y);
+  ASW_PHASE_MARK(t_epi0);
+  if constexpr (C == 64) {
+    // The residual of this layer is its own input, and at C = 64 the whole input row of every
+    // output row still sits in the LDS image (one channel slice) as fp16 hi + lo.  Taking it from
+    // there (x = hi + lo, 2^-22 relative) instead of re-loading it from global memory removes the
+    // load latency from the epilogue, which is 44 % of a workgroup's time at this width
+    // (tests/micro/phase_timing.py).  Read before the first slab barrier: the slab aliases the image.
+    using G = EpiGeom<C, WM, WN>;
+    float4 rpre[TM * G::NSTEP * G::VPL];
+    const int sub = lane / G::LPR, lc = lane % G::LPR;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int st = 0; st < G::NSTEP; ++st) {
+        const int sr = (st * G::NW + wid) * G::RPI + sub;
+        const int trow = (sr >> 5) * (BM / WM) + tm * 32 + (sr & 31);
+        const int irow = POLY ? (trow / BMJ) * RJ + trow % BMJ + (taps - 1) / 2 : trow + pad;
+#pragma unroll
+        for (int q = 0; q < G::VPL; ++q) {
+          const int col = (lc + q * G::LPR) * 4;
+          const half4 hi = *reinterpret_cast<const half4*>(img + irow * RS + col * 2);
+          const half4 lo = *reinterpret_cast<const half4*>(img + irow * RS + 128 + col * 2);
+          rpre[(tm * G::NSTEP + st) * G::VPL + q] = make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1],
+                                                                (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]);
+        }
+      }
+    epilogue<BM, C, WM, WN, true, false, true, false, ResRows<BM, PH, POLY>, true>(
+        acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), ResRows<BM, PH, POLY>{m0, jb, pb, dil, T}, blockIdx, gridDim.y, rpre);
+  } else {
+    epilogue<BM, C, WM, WN, true, false, true, false>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
+                                                      ResRows<BM, PH, POLY>{m0, jb, pb, dil, T}, blockIdx, gridDim.y);
+  }
+#ifdef ASW_PHASE_TIMING
+  {
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+      atomicAdd(&g_phase_cycles[0], t_stage);
+      atomicAdd(&g_phase_cycles[1], t_loop);
+      atomicAdd(&g_phase_cycles[2], t_end - t_epi0);
+      atomicAdd(&g_phase_cycles[3], 1ull);
+    }
+    (void)t_begin;
+  }
+#endif
 }
 
 template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1)>
@@ -734,7 +815,11 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
     // (134 / 140 / 152 rows for 128 outputs) and longer runs of one phase -- as long as a phase
     // (M_out / dil rows) still fills the BM / PH rows the workgroup gives it.
     // Round 2 also measured, for C = 64: 256-row tiles with 4 x 1 waves (221 vs 262 TFLOP/s at
-    // dilation 1) and 2 waves of 128 x 64 (155): the layer is latency bound, fewer resident waves lose.
+    // dilation 1), 2 waves of 128 x 64 (155) and 8 waves 4 x 2 on 256 rows (same wave tile, weight
+    // fragments shared by four waves through L1: 266 vs 268): neither LDS, L2 nor the weight path
+    // is the limit.  Cycle counters per phase (tests/micro/phase_timing.py): a workgroup spends 16 %
+    // staging, 40 % in the k-loop, 44 % in the epilogue; taking the residual from the LDS image
+    // instead of global memory and budgeting registers for 4 waves per SIMD gave +3 %.
     case 64:
       // at C = 64 even dilation 7 is better off as 7 single-phase tiles (halo 6 instead of 42 rows per
       // 128 outputs, image 36 instead of 46 KB -> 4 resident workgroups): 238 -> 257 TFLOP/s
@@ -812,6 +897,17 @@ inline int wide_tile_kind(int B, int M_out, int N, int K) {
 }
 
 }  // namespace
+
+#ifdef ASW_PHASE_TIMING
+extern "C" int asw_debug_phase_cycles(unsigned long long* out4, int reset) {
+  ASW_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_phase_cycles), 4 * sizeof(unsigned long long)));
+  if (reset) {
+    const unsigned long long z[4] = {0, 0, 0, 0};
+    ASW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z));
+  }
+  return ASW_OK;
+}
+#endif
 
 extern "C" int asw_f16x3_overflow_count(int reset, uint32_t* count) {
   ASW_CHECK_ARG(count != nullptr, "f16x3_overflow_count: null pointer");

@@ -1,0 +1,50 @@
+"""Diagnostic: where does a residual-layer workgroup spend its cycles?  Needs the library built
+with -DASW_PHASE_TIMING (tests/micro/libasw_hip_phase.so) selected through
+ASW_LIB_PATH.  Prints, per layer shape, the mean cycles wave 0 of a workgroup spends staging its
+image, in the taps x k-steps loop and in the epilogue."""
+import ctypes
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ["ASW_LIB_PATH"] = os.path.join(ROOT, "tests", "micro", "libasw_hip_phase.so")
+import torch  # noqa: E402
+from acousticswarms_speech_amd import native, ops  # noqa: E402
+
+L = native.lib()
+L.asw_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
+g = torch.Generator().manual_seed(0)
+
+
+def rnd(*s, scale=1.0):
+    return (torch.randn(*s, generator=g) * scale).cuda()
+
+
+def run(C, d, T, B=32, reps=3):
+    x = rnd(B, T, C)
+    w = ops.pack_conv_weight(rnd(C, C, 7, scale=1 / math.sqrt(7 * C)))
+    b, gm, be = rnd(C, scale=0.1), 1 + rnd(C, scale=0.1), rnd(C, scale=0.1)
+    out = torch.empty_like(x)
+    buf = (ctypes.c_ulonglong * 4)()
+    ops.convgemm(x, w, T, C, C, taps=7, dil=d, pad=3 * d, bias=b, relu=True, resid=x, ln=(gm, be), out=out, precision="f16x3")
+    torch.cuda.synchronize()
+    L.asw_debug_phase_cycles(buf, 1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tot = 0.0
+    for _ in range(reps):
+        # ops.convgemm splits the weights on the host per call: time only the launch with events is not possible
+        # from here, so the wall figure below includes that; the cycle counters do not.
+        ops.convgemm(x, w, T, C, C, taps=7, dil=d, pad=3 * d, bias=b, relu=True, resid=x, ln=(gm, be), out=out, precision="f16x3")
+    torch.cuda.synchronize()
+    L.asw_debug_phase_cycles(buf, 1)
+    n = max(1, buf[3])
+    st, lp, ep = buf[0] / n, buf[1] / n, buf[2] / n
+    tot = st + lp + ep
+    print(f"C={C:3d} dil={d:2d} T={T}: per workgroup {tot:8.0f} cycles = staging {st:7.0f} ({100 * st / tot:4.1f} %) + "
+          f"k-loop {lp:7.0f} ({100 * lp / tot:4.1f} %) + epilogue {ep:7.0f} ({100 * ep / tot:4.1f} %); workgroups {n // reps}", flush=True)
+
+
+for C, d, T in ((64, 1, 48128), (64, 7, 48128), (64, 49, 48128), (128, 1, 12032), (256, 1, 3008), (512, 1, 752)):
+    run(C, d, T)
