@@ -667,14 +667,19 @@ void resconv16_kernel(const asw_convgemm_args p) {
         bl[j] = Wl[o];
       }
     };
-    auto compute = [&](int tap, int ks, const half8 (&bh)[TN], const half8 (&bl)[TN]) {
-      half8 ah[TM], al[TM];
+    // A fragments are double buffered in registers, one k-step ahead: left to itself the compiler
+    // keeps ONE fragment register and waits for every ds_read right before its MFMA
+    // (ds_read -> s_waitcnt lgkmcnt(0) -> mfma, four times per k-step), i.e. no LDS read of a wave
+    // ever overlaps its own MFMAs.
+    auto aload = [&](int tap, int ks, half8 (&ah)[TM], half8 (&al)[TM]) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const char* q = img + a_base[i] + tap * tapstep * RS + ks * 32;
         ah[i] = *reinterpret_cast<const half8*>(q);
         al[i] = *reinterpret_cast<const half8*>(q + 128);
       }
+    };
+    auto mma = [&](const half8 (&ah)[TM], const half8 (&al)[TM], const half8 (&bh)[TN], const half8 (&bl)[TN]) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -684,18 +689,30 @@ void resconv16_kernel(const asw_convgemm_args p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
-    // One register buffer per k-step of a tap: the fragment for (tap+1, ks) is requested
+    // One B register buffer per k-step of a tap: the fragment for (tap+1, ks) is requested
     // right after (tap, ks) has been multiplied, i.e. three k-steps (600-1200 MFMA cycles)
     // before its use -- enough to cover an L2 hit without the register cost of a second
     // whole-tap set (which halves occupancy; measured slower for C <= 128).
+    // (measured, T = 48 000 batch 64: C = 64 268 -> 280 TFLOP/s, C = 512 361 -> 368, C = 256 unchanged;
+    // at C = 128 the 32 extra registers cost more than the overlap gains, 305 -> 301, so it keeps
+    // the single buffer)
+    constexpr bool ADB = C != 128;
     half8 qh[QD][TN], ql[QD][TN];
+    half8 ah[ADB ? 2 : 1][TM], al[ADB ? 2 : 1][TM];
     ASW_PHASE_MARK(t_s1);
 #pragma unroll
     for (int ks = 0; ks < QD; ++ks) bload(0, ks, qh[ks], ql[ks]);
+    if (ADB) aload(0, 0, ah[0], al[0]);
     for (int tap = 0; tap < taps; ++tap) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        compute(tap, ks, qh[ks % QD], ql[ks % QD]);
+        if (ADB) {                          // next k-step's A fragments
+          const int nks = (ks + 1) & 3, ntp = tap + (ks == 3 ? 1 : 0);
+          if (ntp < taps) aload(ntp, nks, ah[(ks + 1) & 1], al[(ks + 1) & 1]);
+        } else {
+          aload(tap, ks, ah[0], al[0]);
+        }
+        mma(ah[ADB ? (ks & 1) : 0], al[ADB ? (ks & 1) : 0], qh[ks % QD], ql[ks % QD]);
         const int nk = ks + QD, ntap = tap + nk / 4;               // QD k-steps ahead
         if (ntap < taps) bload(ntap, nk % 4, qh[ks % QD], ql[ks % QD]);
       }
