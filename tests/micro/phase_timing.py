@@ -1,6 +1,14 @@
-"""Diagnostic: where does a residual-layer workgroup spend its cycles?  Needs the library built
-with -DASW_PHASE_TIMING (tests/micro/libasw_hip_phase.so) selected through
-ASW_LIB_PATH.  Prints, per layer shape, the mean cycles wave 0 of a workgroup spends staging its
+"""Diagnostic: where does a residual-layer workgroup spend its cycles?  Needs a diagnostic build of the library with the cycle counters compiled in, selected through
+ASW_LIB_PATH (the .so is not kept in the tree):
+
+    cd acousticswarms-speech_amd && python -c "import native; native.build()" &&
+    hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -DASW_PHASE_TIMING -c csrc/convgemm.hip -o /tmp/convgemm_dbg.o &&
+    hipcc --offload-arch=gfx950 -fPIC -shared -o ../tests/micro/libasw_hip_phase.so /tmp/convgemm_dbg.o \
+        $(ls build/*.o | grep -v convgemm.o)
+
+Round-2 result (T = 48 128, batch 32, before the k-loop was software-pipelined): C = 64: staging 16 %,
+k-loop 40 %, epilogue 44 % of a workgroup's cycles; C = 128: 12 / 51 / 37; C = 256: 8 / 66 / 26;
+C = 512: 6 / 83 / 11.  Prints, per layer shape, the mean cycles wave 0 of a workgroup spends staging its
 image, in the taps x k-steps loop and in the epilogue."""
 import ctypes
 import math
