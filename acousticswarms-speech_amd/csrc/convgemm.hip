@@ -371,8 +371,21 @@ __device__ __forceinline__ void split4(const float4 x, half4& hi, half4& lo) {
   lo = ul.h;
 }
 
+// Four-wave tiles whose LDS footprint lets three workgroups share a CU get a register budget for
+// three waves per SIMD (hipcc otherwise spends ~180 VGPRs -> two): these are the small-K, write- and
+// latency-bound layers, which gain from the third resident workgroup (128x128 tiles: strided conv
+// 211 -> 242, transformer linears 232 -> 269 TFLOP/s, K = 64 / 128 transposed convs +15-20 %).
+// (The 8-wave 256x128 tile squeezed into 128 VGPRs for two workgroups per CU spills and loses:
+// mask encoder 293 vs 312 TFLOP/s on 256x256.)
+template <int BM, int BN, int BK, int WM, int WN>
+constexpr int g16_waves_per_eu() {
+  constexpr long stage = (long)(BM + BN) * (BK + 8) * 2 * 2, slab = (long)(WM * 32) * (BN + 4) * 4;
+  return (WM * WN == 4 && (stage > slab ? stage : slab) <= 53 * 1024) ? 3 : 1;
+}
 template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL, bool A2F>
-__global__ __launch_bounds__(64 * WM * WN) void convgemm16_kernel(const asw_convgemm_args p) {
+__global__ __launch_bounds__(64 * WM * WN)
+__attribute__((amdgpu_waves_per_eu(g16_waves_per_eu<BM, BN, BK, WM, WN>())))
+void convgemm16_kernel(const asw_convgemm_args p) {
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   static_assert(BK % 16 == 0, "k-step of the f16 MFMA");
   constexpr int NT = 64 * WM * WN;           // threads
