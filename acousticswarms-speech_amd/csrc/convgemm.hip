@@ -830,7 +830,8 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
   //            with the weights stationary in registers, 224 VGPRs per wave, was tried: one wave
   //            per SIMD leaves the LDS reads of the A operand exposed -> 160 TFLOP/s.);
   //  C = 128 : B prefetch depth 2 fits 3 waves/SIMD -> 294 -> 312 TFLOP/s (dil 49: 259 -> 279);
-  //  C = 256 : depth 4 and depth 2 tie, keep 4;
+  //  C = 256 : depth 4 and depth 2 tied in round 1; with the A fragments double buffered depth 2
+  //            (3 waves/SIMD) is 1-2 % ahead (322 -> 325, dilation 49: 298 -> 305);
   //  C = 512 : depth 2 fits 2 workgroups per CU -> 346 -> 366 TFLOP/s, except dilation 49 whose
   //            contiguous halo image (294 extra rows) leaves room for one workgroup anyway.
   // Also measured and dropped: 8-wave 128-row tiles for C >= 256 (305 vs 368), and a persistent
@@ -860,7 +861,7 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
     case 128:
       if (!poly) return launch_res<128, 128, 2, 2, 1, 2>(a, s);
       return rows_per_phase >= 48 ? launch_res<128, 128, 2, 2, 2, 2>(a, s) : launch_res<128, 128, 2, 2, 4, 2>(a, s);
-    case 256: return poly ? launch_res<64, 256, 1, 4, 2>(a, s) : launch_res<64, 256, 1, 4, 1>(a, s);
+    case 256: return poly ? launch_res<64, 256, 1, 4, 2, 2>(a, s) : launch_res<64, 256, 1, 4, 1, 2>(a, s);
     case 512:
       // polyphase at C = 512 pays only for long phases: 45 rows per phase (T = 144 000) measured 243
       // TFLOP/s against 307 for the contiguous halo image on the same layer shape at T = 48 000
