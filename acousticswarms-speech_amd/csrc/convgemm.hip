@@ -376,7 +376,8 @@ __device__ __forceinline__ void split4(const float4 x, half4& hi, half4& lo) {
 // latency-bound layers, which gain from the third resident workgroup (128x128 tiles: strided conv
 // 211 -> 242, transformer linears 232 -> 269 TFLOP/s, K = 64 / 128 transposed convs +15-20 %).
 // (The 8-wave 256x128 tile squeezed into 128 VGPRs for two workgroups per CU spills and loses:
-// mask encoder 293 vs 312 TFLOP/s on 256x256.)
+// mask encoder 293 vs 312 TFLOP/s on 256x256; 128x256 with four waves, two independent
+// workgroups per CU: 220.)
 template <int BM, int BN, int BK, int WM, int WN>
 constexpr int g16_waves_per_eu() {
   constexpr long stage = (long)(BM + BN) * (BK + 8) * 2 * 2, slab = (long)(WM * 32) * (BN + 4) * 4;
