@@ -60,6 +60,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // weights; a non-zero count means the next GEMM clipped its input and the f32 mode must be used.
 __device__ unsigned int g_f16x3_overflow = 0;
 
+#ifdef ASW_PHASE_TIMING
+// Diagnostic build only (tests/micro/phase_timing.py): cycles wave 0 of every workgroup spends in
+// each phase of a residual-layer tile, summed over workgroups.  [0] staging (global loads, split,
+// LDS writes, barrier), [1] taps x k-steps, [2] epilogue, [3] workgroups counted.
+__device__ unsigned long long g_phase_cycles[4] = {0, 0, 0, 0};
+// generic 256x256 f16x3 GEMM: [0] waiting at the first barrier of a chunk, [1] register -> LDS deposit
+// + second barrier, [2] global loads of the next chunk + fragment reads + MFMAs, [3] epilogue, [4] workgroups
+__device__ unsigned long long g_gemm_cycles[5] = {0, 0, 0, 0, 0};
+#define ASW_PHASE_MARK(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define ASW_PHASE_MARK(var)
+#endif
 // ------------------------------------------------------------------ shared epilogue
 // tile row -> output row of the batch item (or -1): contiguous tiles
 struct RowsContig {
@@ -376,11 +388,15 @@ __device__ __forceinline__ void split4(const float4 x, half4& hi, half4& lo) {
 // latency-bound layers, which gain from the third resident workgroup (128x128 tiles: strided conv
 // 211 -> 242, transformer linears 232 -> 269 TFLOP/s, K = 64 / 128 transposed convs +15-20 %).
 // (The 8-wave 256x128 tile squeezed into 128 VGPRs for two workgroups per CU spills and loses:
-// mask encoder 293 vs 312 TFLOP/s on 256x256; 128x256 with four waves, two independent
-// workgroups per CU: 220.)
+// mask encoder 293 vs 312 TFLOP/s on 256x256; 128x256 with four waves, i.e. two independent
+// workgroups per CU whose deposit phases could overlap the other's MFMAs: 314 vs 310, a tie.
+// Cycle counters on the 256x256 mask-encoder tile (tests/micro/phase_timing.py): per 32-wide chunk
+// wave 0 spends 1900 cycles waiting at the first barrier (its SIMD mate is still multiplying), 1150
+// depositing the next chunk and 2240 on loads + fragment reads + 48 MFMAs; epilogue 11 % of the tile.)
 template <int BM, int BN, int BK, int WM, int WN>
 constexpr int g16_waves_per_eu() {
   constexpr long stage = (long)(BM + BN) * (BK + 8) * 2 * 2, slab = (long)(WM * 32) * (BN + 4) * 4;
+  if (WM * WN == 4 && (stage > slab ? stage : slab) <= 80 * 1024 && (stage > slab ? stage : slab) > 53 * 1024) return 2;
   return (WM * WN == 4 && (stage > slab ? stage : slab) <= 53 * 1024) ? 3 : 1;
 }
 template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL, bool A2F>
@@ -531,15 +547,40 @@ void convgemm16_kernel(const asw_convgemm_args p) {
     }
   };
 
+#ifdef ASW_PHASE_TIMING
+  unsigned long long tg_wait = 0, tg_store = 0, tg_comp = 0;
+#endif
   gload(0, ra0, rbh0, rbl0);
   for (int kc = 0; kc < nk; ++kc) {
+    ASW_PHASE_MARK(g0);
     __syncthreads();
+    ASW_PHASE_MARK(g1);
     lstore(ra0, rbh0, rbl0);
     __syncthreads();
+    ASW_PHASE_MARK(g2);
     if (kc + 1 < nk) gload(kc + 1, ra0, rbh0, rbl0);
     compute();
+#ifdef ASW_PHASE_TIMING
+    {
+      float sink = acc[0][0][0];
+      asm volatile("" ::"v"(sink));
+      const unsigned long long g3 = __builtin_readcyclecounter();
+      tg_wait += g1 - g0; tg_store += g2 - g1; tg_comp += g3 - g2;
+    }
+#endif
   }
+  ASW_PHASE_MARK(ge0);
   epilogue<BM, BN, WM, WN, LN, STATS, LN, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out}, tile, ncol);
+#ifdef ASW_PHASE_TIMING
+  if (threadIdx.x == 0 && BM == 256 && BN == 256) {
+    const unsigned long long ge1 = __builtin_readcyclecounter();
+    atomicAdd(&g_gemm_cycles[0], tg_wait);
+    atomicAdd(&g_gemm_cycles[1], tg_store);
+    atomicAdd(&g_gemm_cycles[2], tg_comp);
+    atomicAdd(&g_gemm_cycles[3], ge1 - ge0);
+    atomicAdd(&g_gemm_cycles[4], 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ halo-staged residual conv
@@ -561,15 +602,6 @@ void convgemm16_kernel(const asw_convgemm_args p) {
 // its B operand with one coalesced 1 KiB load per fragment, one k-step ahead of the MFMAs
 // (they are L2/L1-resident: a layer's weights are at most 7.3 MB and shared by every
 // workgroup).  No barrier inside the taps x k-steps of a slice.
-#ifdef ASW_PHASE_TIMING
-// Diagnostic build only (tests/micro/phase_timing.md): cycles wave 0 of every workgroup spends in
-// each phase of a residual-layer tile, summed over workgroups.  [0] staging (global loads, split,
-// LDS writes, barrier), [1] taps x k-steps, [2] epilogue, [3] workgroups counted.
-__device__ unsigned long long g_phase_cycles[4] = {0, 0, 0, 0};
-#define ASW_PHASE_MARK(var) const unsigned long long var = __builtin_readcyclecounter()
-#else
-#define ASW_PHASE_MARK(var)
-#endif
 #ifndef ASW_RES128_WAVES
 #define ASW_RES128_WAVES 3
 #endif
@@ -931,6 +963,14 @@ inline int wide_tile_kind(int B, int M_out, int N, int K) {
 }  // namespace
 
 #ifdef ASW_PHASE_TIMING
+extern "C" int asw_debug_gemm_cycles(unsigned long long* out5, int reset) {
+  ASW_HIP(hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_gemm_cycles), 5 * sizeof(unsigned long long)));
+  if (reset) {
+    const unsigned long long z[5] = {0, 0, 0, 0, 0};
+    ASW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_cycles), z, sizeof z));
+  }
+  return ASW_OK;
+}
 extern "C" int asw_debug_phase_cycles(unsigned long long* out4, int reset) {
   ASW_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_phase_cycles), 4 * sizeof(unsigned long long)));
   if (reset) {

@@ -56,3 +56,30 @@ def run(C, d, T, B=32, reps=3):
 
 for C, d, T in ((64, 1, 48128), (64, 7, 48128), (64, 49, 48128), (128, 1, 12032), (256, 1, 3008), (512, 1, 752)):
     run(C, d, T)
+
+
+def run_mask(B=32, reps=3):
+    """Generic 256x256 GEMM on the mask-encoder shape."""
+    T, C, E, F = 48128, 64, 2048, 3008
+    L.asw_debug_gemm_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    x = rnd(B, T, C)
+    w = ops.pack_conv_weight(rnd(E, C, 33, scale=1 / math.sqrt(33 * C)))
+    b = rnd(E, scale=0.1)
+    y = rnd(B, F, E)
+    buf = (ctypes.c_ulonglong * 5)()
+    ops.convgemm(x, w, F, E, C, taps=33, stride=16, pad=16, bias=b, relu=True, mul=y, out=y, precision="f16x3")
+    torch.cuda.synchronize()
+    L.asw_debug_gemm_cycles(buf, 1)
+    for _ in range(reps):
+        ops.convgemm(x, w, F, E, C, taps=33, stride=16, pad=16, bias=b, relu=True, mul=y, out=y, precision="f16x3")
+    torch.cuda.synchronize()
+    L.asw_debug_gemm_cycles(buf, 1)
+    n = max(1, buf[4])
+    wt, st, cp, ep = (buf[i] / n for i in range(4))
+    tot = wt + st + cp + ep
+    print(f"mask encoder 256x256 tile, 66 chunks: per workgroup {tot:8.0f} cycles = barrier wait {wt:7.0f} ({100 * wt / tot:4.1f} %) + "
+          f"deposit {st:7.0f} ({100 * st / tot:4.1f} %) + loads/MFMA {cp:7.0f} ({100 * cp / tot:4.1f} %) + epilogue {ep:7.0f} "
+          f"({100 * ep / tot:4.1f} %); per chunk: wait {wt / 66:.0f} deposit {st / 66:.0f} compute {cp / 66:.0f}", flush=True)
+
+
+run_mask()
