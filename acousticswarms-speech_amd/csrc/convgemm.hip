@@ -583,6 +583,180 @@ void convgemm16_kernel(const asw_convgemm_args p) {
 #endif
 }
 
+// ------------------------------------------------------------------ pipelined wide-tile GEMM
+// The 8-wave 256-column tiles (mask encoder, strided / transposed convolutions, big linears) as a
+// software pipeline with ONE barrier per 32-wide chunk instead of two (cycle counters on the
+// two-barrier kernel above, mask-encoder shape: per chunk wave 0 spent 1150 cycles depositing the
+// next chunk with every MFMA pipe of the workgroup idle, tests/micro/phase_timing.py):
+//  * B never touches LDS: the weights are pre-packed in MFMA-fragment order (asw_pack_fragments_f16,
+//    the layout of the residual kernel), each wave pulls its two column fragments per k-step with
+//    coalesced 1 KiB loads, QDB k-steps ahead of their use (L2-resident: one column tile of the
+//    largest matrix is 2.1 MB);
+//  * A (fp32 activations) is split to fp16 hi / lo while it is deposited, into a two-stage LDS ring:
+//    the rows of chunk k+1 are fetched before, and deposited after, the MFMAs of chunk k, so the
+//    deposit of one wave overlaps the MFMAs of the others and only the ring hand-over needs a barrier.
+// Same tiling (wave tile BM/2 x 64), same epilogue, same XCD-aware tile order as the kernel above.
+// Measured (T = 48 000, batch 64): mask encoder 312 -> 332 TFLOP/s, strided / transposed convolutions
+// +3-6 %.  64-wide chunks (half the barriers, 147 KB ring) spill and lose: 304.
+template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
+void convgemm16p_kernel(const asw_convgemm_args p) {
+  constexpr int BN = 256, WM = 2, WN = 4, NT = 512, QDB = 2;
+  constexpr int LDH = BK + 8, KV = BK / 4;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_VEC = (BM * KV + NT - 1) / NT;
+  constexpr int STAGE = 2 * BM * LDH;              // halves per ring stage (hi image + lo image)
+
+  extern __shared__ __align__(16) float smem[];
+  _Float16* ring = reinterpret_cast<_Float16*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int ncol = p.N / BN, nrt = (p.M_out + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int R = (slot / ncol) * 8 + xcd;                      // (batch item, row tile) index, XCD-aware order
+  if (R >= p.B * nrt) return;
+  const dim3 tile(R % nrt, slot % ncol, R / nrt);
+  const int b = tile.z, m0 = tile.x * BM, n0 = tile.y * BN;
+  const int cpb = p.Cin / BK;
+  const int nk = p.taps * cpb;
+  const float* __restrict__ Ab = p.A + (long)b * p.a_batch_stride;
+  const float* __restrict__ A2b = p.A2 ? p.A2 + (long)b * p.a_batch_stride : nullptr;
+  const half8* __restrict__ Wh = reinterpret_cast<const half8*>(p.Wf_hi);
+  const half8* __restrict__ Wl = reinterpret_cast<const half8*>(p.Wf_lo);
+  const int NTF = p.N / 32;                        // column fragments across N
+  const int nt0 = n0 / 32 + wn * TN;
+
+  float4 ra[A_VEC];
+  long a_row[A_VEC];
+  bool a_ok[A_VEC];
+#pragma unroll
+  for (int v = 0; v < A_VEC; ++v) {
+    const int idx = tid + v * NT;
+    const int row = idx / KV, cv = idx - row * KV;
+    a_row[v] = ((long)(m0 + row) * p.stride - p.pad) * p.a_row_stride + cv * 4;
+    a_ok[v] = (idx < BM * KV) && (m0 + row < p.M_out);
+  }
+  const long tap_step = (long)p.dil * p.a_row_stride;
+  const __amdgpu_buffer_rsrc_t rA = act_rsrc(Ab, p.a_len);
+  const __amdgpu_buffer_rsrc_t rA2 = act_rsrc(A2F ? A2b : Ab, p.a_len);
+
+  auto gload = [&](int kc) {
+    const int tap = kc / cpb;
+    const long koff = tap * tap_step + (kc - tap * cpb) * BK;
+#pragma unroll
+    for (int v = 0; v < A_VEC; ++v) {
+      const long e = a_row[v] + koff;
+      float4 x = act_load4(rA, e, a_ok[v]);
+      if (A2F) {
+        const float4 y = act_load4(rA2, e, a_ok[v]);
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
+      ra[v] = x;
+    }
+  };
+  auto deposit = [&](int stage) {
+    _Float16* Ah = ring + stage * STAGE;
+    _Float16* Al = Ah + BM * LDH;
+#pragma unroll
+    for (int v = 0; v < A_VEC; ++v) {
+      const int idx = tid + v * NT;
+      const int row = idx / KV, cv = idx - row * KV;
+      if (idx < BM * KV) {
+        half4 hi, lo;
+        split4(ra[v], hi, lo);
+        *reinterpret_cast<half4*>(Ah + row * LDH + cv * 4) = hi;
+        *reinterpret_cast<half4*>(Al + row * LDH + cv * 4) = lo;
+      }
+    }
+  };
+  auto bload = [&](int kg, half8 (&bh)[TN], half8 (&bl)[TN]) {          // kg = global k-step (16 K each)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const long o = ((long)kg * NTF + nt0 + j) * 64 + lane;
+      bh[j] = Wh[o];
+      bl[j] = Wl[o];
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int a_off = (wm * (BM / WM) + (lane & 31)) * LDH + (lane >> 5) * 8;
+  half8 qh[QDB][TN], ql[QDB][TN];                  // B fragments of the next QDB k-steps
+  const int nks = nk * (BK / 16);                  // k-steps in all
+#pragma unroll
+  for (int q = 0; q < QDB; ++q) bload(q, qh[q], ql[q]);
+  gload(0);
+  deposit(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) gload(kc + 1);                // in flight under the MFMAs of this chunk
+    const _Float16* Ah = ring + (kc & 1) * STAGE;
+    const _Float16* Al = Ah + BM * LDH;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      half8 ah[TM], al[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(Ah + a_off + i * 32 * LDH + ks * 16);
+        al[i] = *reinterpret_cast<const half8*>(Al + a_off + i * 32 * LDH + ks * 16);
+      }
+      constexpr int KS = BK / 16;
+      const int q = ks % QDB;                      // B register buffer of this k-step
+      static_assert(KS % QDB == 0, "the B ring must divide the k-steps of a chunk");
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], qh[q][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], ql[q][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], qh[q][j], acc[i][j], 0, 0, 0);
+        }
+      const int kg = kc * KS + ks + QDB;           // same slot, QDB k-steps ahead
+      if (kg < nks) bload(kg, qh[q], ql[q]);
+      // deposit of the next chunk between the two k-steps: its conversions and LDS writes issue in
+      // the shadow of this wave's own MFMAs (the other stage was last read one chunk ago, before the
+      // previous barrier)
+      if (ks == KS / 2 - 1 && kc + 1 < nk) deposit((kc + 1) & 1);
+    }
+    __syncthreads();
+  }
+  epilogue<BM, BN, WM, WN, false, STATS, false, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out},
+                                                     tile, ncol);
+}
+
+template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32>
+int launch_pipe(const asw_convgemm_args& a, hipStream_t s) {
+  constexpr int BN = 256;
+  constexpr size_t ring = (size_t)2 * 2 * BM * (BK + 8) * sizeof(_Float16);
+  constexpr size_t slab = (size_t)(2 * 32) * (BN + 4) * sizeof(float);
+  constexpr size_t smem = ring > slab ? ring : slab;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  const void* kern = reinterpret_cast<const void*>(convgemm16p_kernel<BM, STATS, MUL, A2F, BK>);
+  static asw::SmemAttr attr;                            // per device
+  if (int rc = attr.ensure(kern, smem)) return rc;
+  ASW_CHECK_ARG(A2F == (a.A2 != nullptr), "convgemm: skip operand variant mismatch");
+  ASW_CHECK_ARG(a.Cin % BK == 0 && a.N % BN == 0, "convgemm: pipelined tile needs Cin %% BK == 0 and N %% 256 == 0");
+  const long nrt = asw::cdiv(a.M_out, BM);
+  dim3 grid(((nrt * a.B + 7) / 8) * 8 * (a.N / BN), 1, 1);
+  std::string pn = asw::prof_name(MUL ? "convgemm16pm" : "convgemm16p", BM, BN, BK, false, STATS);
+  if (asw::prof_detail()) {
+    char sh[64];
+    snprintf(sh, sizeof sh, "[B%d M%d N%d K%d s%d]", a.B, a.M_out, a.N, a.taps * a.Cin, a.stride);
+    pn += sh;
+  }
+  asw::ProfScope prof(s, pn, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
+  hipLaunchKernelGGL((convgemm16p_kernel<BM, STATS, MUL, A2F, BK>), grid, dim3(512), smem, s, a);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
 // ------------------------------------------------------------------ halo-staged residual conv
 // DilatedResidualLayer (network.py:57-68) in f16x3 arithmetic: out = LN(ReLU(conv_d(x)+b) + x).
 // The workgroup owns BM output rows x all C channels.  For each 64-channel slice of the
@@ -1095,6 +1269,14 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
       // f16x3 is bound by the bytes each CU can pull per cycle, so take the largest tile the
       // shape fills: 256x256 (8 waves, 1/32 B per MAC), 256x128, else 128x128 (1/16 B per MAC)
       const int t = wide_tile_kind(a.B, a.M_out, a.N, a.taps * a.Cin);
+      static const bool no_pipe = getenv("ASW_NO_PIPE") != nullptr;           // A/B switch for measurements
+      // (192-row tiles, i.e. a single row tile per item and a long K, stay on the two-barrier kernel:
+      // with so little reuse of a weight fragment the global B path loses, 296 vs 322 TFLOP/s)
+      if (!no_pipe && a.Wf_hi && a.Wf_lo && t == 2 && (a.taps * a.Cin) % 16 == 0 && a.N % 32 == 0) {
+        if (a.mul) return launch_pipe<256, false, true, false>(a, s);
+        if (stats && a.A2) return launch_pipe<256, true, false, true>(a, s);
+        return stats ? launch_pipe<256, true, false, false>(a, s) : launch_pipe<256, false, false, false>(a, s);
+      }
       if (t == 3) {
         if (a.mul) return launch<192, 256, 32, 2, 4, false, false, true, true>(a, s);
         if (stats && a.A2) return launch<192, 256, 32, 2, 4, false, true, false, true, true>(a, s);

@@ -48,6 +48,15 @@ struct WBuf {
     if (fhi) (void)hipFree(fhi);
     if (flo) (void)hipFree(flo);
   }
+  // GEMM weight Wt[N][K] in every form the kernels take: fp32, fp16 hi / lo row-major, and -- when the
+  // shape allows (N % 32 == 0, K % 16 == 0) -- hi / lo in MFMA-fragment order for the kernels that
+  // pull their B operand straight from global memory (residual layers, pipelined wide tiles)
+  int upload_gemm(const std::vector<float>& h, int N, int K) {
+    int rc = upload(h);
+    if (rc) return rc;
+    if (N % 32 == 0 && K % 16 == 0 && (size_t)N * K == h.size()) return upload_frags(h, N, K);
+    return ASW_OK;
+  }
   int upload(const std::vector<float>& h) {
     int rc = f32.upload(h);
     if (rc) return rc;
@@ -70,6 +79,8 @@ struct WBuf {
     int rc = asw_pack_fragments_f16(h.data(), N, K, vh.data(), vl.data(), &sh);
     if (rc) return rc;
     if (sh != shift) return asw::set_error(ASW_ERR_STATE, "fragment pack: inconsistent weight shift");
+    if (fhi) { (void)hipFree(fhi); fhi = nullptr; }
+    if (flo) { (void)hipFree(flo); flo = nullptr; }
     if (hipMalloc(&fhi, h.size() * 2) != hipSuccess || hipMalloc(&flo, h.size() * 2) != hipSuccess)
       return asw::set_error(ASW_ERR_NOMEM, "hipMalloc(%zu halves)", h.size());
     ASW_HIP(hipMemcpy(fhi, vh.data(), h.size() * 2, hipMemcpyHostToDevice));

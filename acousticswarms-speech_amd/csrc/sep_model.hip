@@ -504,7 +504,9 @@ extern "C" int asw_sep_finalize(asw_sep* m) {
     const std::string p = "encoder.module_list." + std::to_string(i);
     EncBlock& e = m->enc[i];
     if ((rc = pack_res_layers(m->raw, p, m->enc_cin[i], K, c.residual_layers, c.residual_dilation_factor, e.res))) return rc;
-    UP(e.down_wt, pack_conv(P(m, p + ".conv1.weight"), 2 * m->enc_cout[i], m->enc_cin[i], K, nullptr));
+    if ((rc = e.down_wt.upload_gemm(pack_conv(P(m, p + ".conv1.weight"), 2 * m->enc_cout[i], m->enc_cin[i], K, nullptr),
+                                    2 * m->enc_cout[i], m->enc_cin[i] * K)))
+      return rc;
     UP(e.bias, P(m, p + ".conv1.bias"));
     UP(e.gn_g, P(m, p + ".norm1.weight"));
     UP(e.gn_b, P(m, p + ".norm1.bias"));
@@ -524,7 +526,7 @@ extern "C" int asw_sep_finalize(asw_sep* m) {
         bb[(size_t)r * co2 + n] = b[n];
         for (int cc = 0; cc < ci; ++cc) wt[((size_t)r * co2 + n) * ci + cc] = w[((size_t)cc * co2 + n) * st + r];
       }
-    UP(dd.up_wt, wt);
+    if ((rc = dd.up_wt.upload_gemm(wt, st * co2, ci))) return rc;
     UP(dd.up_bias, bb);
     UP(dd.gn_g, P(m, p + ".norm1.weight"));
     UP(dd.gn_b, P(m, p + ".norm1.bias"));
@@ -599,7 +601,7 @@ extern "C" int asw_sep_finalize(asw_sep* m) {
     UP(m->byp_wt, wt);
     UP(m->byp_b, P(m, "reference_bypass.bias"));
   }
-  UP(m->mask_wt, pack_conv(P(m, "mask_encoder.weight"), E, c.channels, EK, nullptr));
+  if ((rc = m->mask_wt.upload_gemm(pack_conv(P(m, "mask_encoder.weight"), E, c.channels, EK, nullptr), E, c.channels * EK))) return rc;
   UP(m->mask_b, P(m, "mask_encoder.bias"));
   {
     const std::vector<float>& w = P(m, "output_decoder.weight");     // [E][1][EK]

@@ -175,8 +175,9 @@ int get_gates(asw_spot* m, float w0, float w1, GateSet** out) {
     const std::string p = "encoder.module_list." + std::to_string(i);
     const std::vector<float> g = gate_of(P(m, p + ".embed1.weight"), P(m, p + ".embed1.bias"), w0, w1);
     gs->down_wt.emplace_back(new WBuf());
-    int rc = gs->down_wt.back()->upload(
-        pack_conv(P(m, p + ".conv1.weight"), 2 * m->enc_cout[i], m->enc_cin[i], c.kernel_size, g.data()));
+    int rc = gs->down_wt.back()->upload_gemm(
+        pack_conv(P(m, p + ".conv1.weight"), 2 * m->enc_cout[i], m->enc_cin[i], c.kernel_size, g.data()),
+        2 * m->enc_cout[i], m->enc_cin[i] * c.kernel_size);
     if (rc) return rc;
   }
   for (int i = 0; i < c.depth; ++i) {
@@ -197,7 +198,7 @@ int get_gates(asw_spot* m, float w0, float w1, GateSet** out) {
     gs->up_wt.emplace_back(new WBuf());
     gs->up_bias.emplace_back(new DevBuf());
     int rc;
-    if ((rc = gs->up_wt.back()->upload(wt))) return rc;
+    if ((rc = gs->up_wt.back()->upload_gemm(wt, s * co2, ci))) return rc;
     if ((rc = gs->up_bias.back()->upload(bb))) return rc;
   }
   *out = gs.get();
@@ -486,10 +487,17 @@ extern "C" int asw_spot_finalize(asw_spot* m) {
   for (int l = 0; l < c.num_transformer_layers; ++l) {
     const std::string p = "bottleneck.transf.layers." + std::to_string(l);
     TfLayer& t = m->tf[l];
-    UP(t.w_in, P(m, p + ".self_attn.in_proj_weight")); UP(t.b_in, P(m, p + ".self_attn.in_proj_bias"));
-    UP(t.w_out, P(m, p + ".self_attn.out_proj.weight")); UP(t.b_out, P(m, p + ".self_attn.out_proj.bias"));
-    UP(t.w1, P(m, p + ".linear1.weight")); UP(t.b1, P(m, p + ".linear1.bias"));
-    UP(t.w2, P(m, p + ".linear2.weight")); UP(t.b2, P(m, p + ".linear2.bias"));
+    {
+      const int dm = m->enc_cout.back(), ff = c.ffw_dim;
+      if ((rc = t.w_in.upload_gemm(P(m, p + ".self_attn.in_proj_weight"), 3 * dm, dm))) return rc;
+      if ((rc = t.w_out.upload_gemm(P(m, p + ".self_attn.out_proj.weight"), dm, dm))) return rc;
+      if ((rc = t.w1.upload_gemm(P(m, p + ".linear1.weight"), ff, dm))) return rc;
+      if ((rc = t.w2.upload_gemm(P(m, p + ".linear2.weight"), dm, ff))) return rc;
+    }
+    UP(t.b_in, P(m, p + ".self_attn.in_proj_bias"));
+    UP(t.b_out, P(m, p + ".self_attn.out_proj.bias"));
+    UP(t.b1, P(m, p + ".linear1.bias"));
+    UP(t.b2, P(m, p + ".linear2.bias"));
     UP(t.n1g, P(m, p + ".norm1.weight")); UP(t.n1b, P(m, p + ".norm1.bias"));
     UP(t.n2g, P(m, p + ".norm2.weight")); UP(t.n2b, P(m, p + ".norm2.bias"));
   }
@@ -503,7 +511,7 @@ extern "C" int asw_spot_finalize(asw_spot* m) {
     UP(m->byp_wt, wt);
     UP(m->byp_b, P(m, "reference_bypass.bias"));
   }
-  UP(m->mask_wt, pack_conv(P(m, "mask_encoder.weight"), E, c.channels, EK, nullptr));
+  if ((rc = m->mask_wt.upload_gemm(pack_conv(P(m, "mask_encoder.weight"), E, c.channels, EK, nullptr), E, c.channels * EK))) return rc;
   UP(m->mask_b, P(m, "mask_encoder.bias"));
   {
     const std::vector<float>& w = P(m, "output_decoder.weight");     // [E][1][EK]
