@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 
 prefix, out_path = sys.argv[1], sys.argv[2]
-DOM = "convgemm16_kernel<256, 256, 32, 2, 4, false, false, true, false>"
+DOM = "convgemm16p_kernel<256, false, true, false, 32>"      # mask encoder on the pipelined wide-tile kernel
 
 
 def short(name):
@@ -41,7 +41,7 @@ wr, _ = write[DOM]
 rec = {
     "_comment": "HBM / fabric traffic of the dominant kernel of `python bench.py` (mask encoder, internal batch 256, T=48000), "
                 "from separate rocprofv3 --pmc passes over that very command; per-launch means.",
-    "kernel": "convgemm16m<256,256,32,plain>", "rocprof_name": DOM, "batch": B, "dispatches_averaged": fn,
+    "kernel": "convgemm16pm<256,256,32,plain>", "rocprof_name": DOM, "batch": B, "dispatches_averaged": fn,
     "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB": wr,
     "read_bytes_corrected_2x": int(fr * 1024 * 2), "write_bytes": int(wr * 1024),
     "corrected_bytes_per_launch": int(fr * 1024 * 2 + wr * 1024),
