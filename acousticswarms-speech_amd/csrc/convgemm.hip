@@ -36,6 +36,7 @@
 // rows: + residual, * gate tensor, LayerNorm over the row (two-pass, wave shuffles),
 // GroupNorm partial sums, coalesced row stores.
 #include <cstdlib>
+#include <type_traits>
 
 #include "asw_common.h"
 
@@ -598,10 +599,13 @@ void convgemm16_kernel(const asw_convgemm_args p) {
 // Same tiling (wave tile BM/2 x 64), same epilogue, same XCD-aware tile order as the kernel above.
 // Measured (T = 48 000, batch 64): mask encoder 312 -> 332 TFLOP/s, strided / transposed convolutions
 // +3-6 %.  64-wide chunks (half the barriers, 147 KB ring) spill and lose: 304.
+#ifndef ASW_PIPE_QDB
+#define ASW_PIPE_QDB 2
+#endif
 template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void convgemm16p_kernel(const asw_convgemm_args p) {
-  constexpr int BN = 256, WM = 2, WN = 4, NT = 512, QDB = 2;
+  constexpr int BN = 256, WM = 2, WN = 4, NT = 512, QDB = ASW_PIPE_QDB;
   constexpr int LDH = BK + 8, KV = BK / 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_VEC = (BM * KV + NT - 1) / NT;
@@ -695,21 +699,24 @@ void convgemm16p_kernel(const asw_convgemm_args p) {
   gload(0);
   deposit(0);
   __syncthreads();
-  for (int kc = 0; kc < nk; ++kc) {
+  constexpr int KS = BK / 16;
+  static_assert(KS % QDB == 0 || QDB == 2 * KS, "the B ring is one or two chunks deep");
+  // One chunk; PAR = chunk parity, compile-time so that ring stage and B buffer indices are static
+  // (the loop below is unrolled by two).
+  auto chunk = [&](int kc, auto par) {
+    constexpr int PAR = decltype(par)::value;
     if (kc + 1 < nk) gload(kc + 1);                // in flight under the MFMAs of this chunk
-    const _Float16* Ah = ring + (kc & 1) * STAGE;
+    const _Float16* Ah = ring + PAR * STAGE;
     const _Float16* Al = Ah + BM * LDH;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       half8 ah[TM], al[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const half8*>(Ah + a_off + i * 32 * LDH + ks * 16);
         al[i] = *reinterpret_cast<const half8*>(Al + a_off + i * 32 * LDH + ks * 16);
       }
-      constexpr int KS = BK / 16;
-      const int q = ks % QDB;                      // B register buffer of this k-step
-      static_assert(KS % QDB == 0, "the B ring must divide the k-steps of a chunk");
+      const int q = (PAR * KS + ks) % QDB;         // B register buffer of this k-step
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -720,12 +727,16 @@ void convgemm16p_kernel(const asw_convgemm_args p) {
         }
       const int kg = kc * KS + ks + QDB;           // same slot, QDB k-steps ahead
       if (kg < nks) bload(kg, qh[q], ql[q]);
-      // deposit of the next chunk between the two k-steps: its conversions and LDS writes issue in
-      // the shadow of this wave's own MFMAs (the other stage was last read one chunk ago, before the
+      // deposit of the next chunk between the k-steps: its conversions and LDS writes issue in the
+      // shadow of this wave's own MFMAs (the other stage was last read one chunk ago, before the
       // previous barrier)
-      if (ks == KS / 2 - 1 && kc + 1 < nk) deposit((kc + 1) & 1);
+      if (ks == KS / 2 - 1 && kc + 1 < nk) deposit(PAR ^ 1);
     }
     __syncthreads();
+  };
+  for (int kc = 0; kc < nk; kc += 2) {
+    chunk(kc, std::integral_constant<int, 0>{});
+    if (kc + 1 < nk) chunk(kc + 1, std::integral_constant<int, 1>{});
   }
   epilogue<BM, BN, WM, WN, false, STATS, false, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out},
                                                      tile, ncol);
