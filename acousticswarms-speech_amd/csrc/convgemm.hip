@@ -602,16 +602,18 @@ void convgemm16_kernel(const asw_convgemm_args p) {
 #ifndef ASW_PIPE_QDB
 #define ASW_PIPE_QDB 2
 #endif
-template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
-void convgemm16p_kernel(const asw_convgemm_args p) {
+// Main loop of one 256-column tile: picks the tile of this workgroup (false: none, the whole workgroup
+// leaves), runs the K loop and returns the accumulators (wave (wm, wn) of 2 x 4 holds rows
+// wm*BM/2 + 32*i.., columns wn*64 + 32*j..).  Ends on a barrier: the ring is free for the epilogue.
+template <int BM, bool A2F, int BK>
+__device__ __forceinline__ bool pipe_mainloop(const asw_convgemm_args& p, float* smem, floatx16 (&acc)[BM / 64][2],
+                                              dim3& tile_out, int& ncol_out) {
   constexpr int BN = 256, WM = 2, WN = 4, NT = 512, QDB = ASW_PIPE_QDB;
   constexpr int LDH = BK + 8, KV = BK / 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_VEC = (BM * KV + NT - 1) / NT;
   constexpr int STAGE = 2 * BM * LDH;              // halves per ring stage (hi image + lo image)
 
-  extern __shared__ __align__(16) float smem[];
   _Float16* ring = reinterpret_cast<_Float16*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -619,8 +621,10 @@ void convgemm16p_kernel(const asw_convgemm_args p) {
   const int ncol = p.N / BN, nrt = (p.M_out + BM - 1) / BM;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int R = (slot / ncol) * 8 + xcd;                      // (batch item, row tile) index, XCD-aware order
-  if (R >= p.B * nrt) return;
+  if (R >= p.B * nrt) return false;
   const dim3 tile(R % nrt, slot % ncol, R / nrt);
+  tile_out = tile;
+  ncol_out = ncol;
   const int b = tile.z, m0 = tile.x * BM, n0 = tile.y * BN;
   const int cpb = p.Cin / BK;
   const int nk = p.taps * cpb;
@@ -683,7 +687,6 @@ void convgemm16p_kernel(const asw_convgemm_args p) {
     }
   };
 
-  floatx16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -738,8 +741,190 @@ void convgemm16p_kernel(const asw_convgemm_args p) {
     chunk(kc, std::integral_constant<int, 0>{});
     if (kc + 1 < nk) chunk(kc + 1, std::integral_constant<int, 1>{});
   }
-  epilogue<BM, BN, WM, WN, false, STATS, false, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift), RowsContig{m0, p.M_out},
-                                                     tile, ncol);
+  return true;
+}
+
+template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
+void convgemm16p_kernel(const asw_convgemm_args p) {
+  constexpr int BN = 256, WM = 2, WN = 4;
+  extern __shared__ __align__(16) float smem[];
+  floatx16 acc[BM / 64][2];
+  dim3 tile;
+  int ncol;
+  if (!pipe_mainloop<BM, A2F, BK>(p, smem, acc, tile, ncol)) return;
+  epilogue<BM, BN, WM, WN, false, STATS, false, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
+                                                     RowsContig{(int)tile.x * BM, p.M_out}, tile, ncol);
+}
+
+// ------------------------------------------------------------------ mask path in one kernel
+// reference_bypass, mask_encoder and the output_decoder taps (network.py:327-349,397-405) without the
+// 2048-channel latents ever reaching memory:
+//   taps[f][j] = sum_e relu(mask_enc(x)[f][e] + b_e) * relu(bypass(ref)[f][e] + c_e) * D[e][j]
+// The main loop is the pipelined GEMM above (mask encoder, K = taps*Cin).  Epilogue, per 256 x 256 tile:
+//  A. each wave computes the bypass tile of its own 32 x 32 accumulator blocks with nine more MFMAs
+//     (K = 33 padded to 48; the frames of the reference channel are read straight from global memory
+//     in A-fragment order) and gates the accumulators in registers;
+//  B. the gated latent goes through an LDS slab, 128 rows at a time, and comes back in A-fragment
+//     order for the decoder contraction over the tile's 256 latent channels: eight waves = four
+//     32-row blocks x two 32-tap blocks, 48 MFMAs each.  The result is a PARTIAL tap product (this
+//     column tile's share of the sum over e); the overlap-add kernel adds the N/256 partials.
+// Per candidate (T = 48 000) this writes 8 x 3008 x 33 floats instead of writing the bypass latent,
+// reading it, writing the gated latent and reading that again (4 x 24.6 MB).
+template <int BM, int KSB>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
+void maskpath16p_kernel(const asw_convgemm_args p, const asw_maskpath_args mf) {
+  constexpr int BN = 256, WN = 4, TM = BM / 64, TN = 2, LDC = BN + 4, BK = 32;
+  static_assert(BM == 256, "slab passes are written for 2 x 128 rows");
+  extern __shared__ __align__(16) float smem[];
+  floatx16 acc[TM][TN];
+  dim3 tile;
+  int ncol;
+  if (!pipe_mainloop<BM, false, BK>(p, smem, acc, tile, ncol)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int b = tile.z, m0 = tile.x * BM, n0 = tile.y * BN;
+  const float acc_scale = __builtin_ldexpf(1.0f, -p.w_shift);
+  const float byp_scale = __builtin_ldexpf(1.0f, -mf.byp_shift), dec_scale = __builtin_ldexpf(1.0f, -mf.dec_shift);
+  // ---- A: bypass tile + gating, in registers
+  const __amdgpu_buffer_rsrc_t rR = act_rsrc(mf.ref + (long)b * mf.ref_batch_stride, mf.ref_len);
+  const half8* __restrict__ Bh = reinterpret_cast<const half8*>(mf.byp_hi);
+  const half8* __restrict__ Bl = reinterpret_cast<const half8*>(mf.byp_lo);
+  const int NTF = p.N / 32;
+  float amax = 0.f;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int nt = n0 / 32 + wn * TN + tn;
+    const int col = nt * 32 + (lane & 31);
+    const float bm = p.bias ? p.bias[col] : 0.f, bb = mf.byp_bias ? mf.byp_bias[col] : 0.f;
+    half8 wh[KSB], wl[KSB];
+#pragma unroll
+    for (int ks = 0; ks < KSB; ++ks) {
+      wh[ks] = Bh[((long)ks * NTF + nt) * 64 + lane];
+      wl[ks] = Bl[((long)ks * NTF + nt) * 64 + lane];
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int f = m0 + wm * (BM / 2) + tm * 32 + (lane & 31);
+      const bool ok = f < p.M_out;
+      floatx16 bp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSB; ++ks) {
+        const long e = (long)f * mf.ref_hop + ks * 16 + (lane >> 5) * 8;
+        const float4 x0 = act_load4(rR, e, ok), x1 = act_load4(rR, e + 4, ok);
+        half4 h0, l0, h1, l1;
+        split4(x0, h0, l0);
+        split4(x1, h1, l1);
+        const half8 ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const half8 al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        bp = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[ks], bp, 0, 0, 0);
+        bp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[ks], bp, 0, 0, 0);
+        bp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[ks], bp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = fmaxf(acc[tm][tn][r] * acc_scale + bm, 0.f) * fmaxf(bp[r] * byp_scale + bb, 0.f);
+        amax = fmaxf(amax, v);
+        acc[tm][tn][r] = v;
+      }
+    }
+  }
+  // the latent is split to fp16 halves below: same range guard as a latent written for a later GEMM
+  if (!(amax <= 65504.f)) atomicAdd(&g_f16x3_overflow, 1u);
+  // ---- B: decoder contraction through the slab, rows [pass*128, pass*128 + 128) of the tile per pass
+  float* Ct = smem;
+  const half8* __restrict__ Dh = reinterpret_cast<const half8*>(mf.dec_hi);
+  const half8* __restrict__ Dl = reinterpret_cast<const half8*>(mf.dec_lo);
+  const int ft = wid & 3, tt = wid >> 2;                       // 32-row block, 32-tap block of this wave
+  float* __restrict__ outp = mf.taps + ((long)tile.y * p.B + b) * p.M_out * 64;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();                                 // (pass 0: the main loop ended on a barrier)
+    if (wm == pass) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int col = wn * 64 + tn * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Ct[row * LDC + col] = acc[tm][tn][r];
+          }
+        }
+    }
+    __syncthreads();
+    floatx16 tp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tp[r] = 0.f;
+    const float* src = Ct + (ft * 32 + (lane & 31)) * LDC + (lane >> 5) * 8;
+#pragma unroll 4
+    for (int ks = 0; ks < BN / 16; ++ks) {
+      const float4 x0 = *reinterpret_cast<const float4*>(src + ks * 16);
+      const float4 x1 = *reinterpret_cast<const float4*>(src + ks * 16 + 4);
+      const long o = ((long)(n0 / 16 + ks) * 2 + tt) * 64 + lane;
+      const half8 dh = Dh[o], dl = Dl[o];
+      half4 h0, l0, h1, l1;
+      split4(x0, h0, l0);
+      split4(x1, h1, l1);
+      const half8 ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      const half8 al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      tp = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, dh, tp, 0, 0, 0);
+      tp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dl, tp, 0, 0, 0);
+      tp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dh, tp, 0, 0, 0);
+    }
+    const int j = tt * 32 + (lane & 31);
+    if (j < mf.dec_taps) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = m0 + pass * 128 + ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (f < p.M_out) outp[(long)f * 64 + j] = tp[r] * dec_scale;
+      }
+    }
+  }
+}
+
+int launch_mask_path(const asw_maskpath_args* args, void* stream) {
+  ASW_CHECK_ARG(args, "mask_path: null argument block");
+  const asw_maskpath_args& m = *args;
+  asw_convgemm_args a = m.enc;
+  hipStream_t s = asw::as_stream(stream);
+  constexpr int BM = 256, BN = 256, BK = 32, KSB = 3;
+  ASW_CHECK_ARG(a.A && a.Wf_hi && a.Wf_lo && m.ref && m.byp_hi && m.byp_lo && m.dec_hi && m.dec_lo && m.taps,
+                "mask_path: null pointer (fragment-order weights are required)");
+  ASW_CHECK_ARG(a.B > 0 && a.M_out > 0 && a.N % BN == 0 && a.Cin % BK == 0 && a.taps > 0 && a.stride > 0,
+                "mask_path: shape (N %% 256 == 0, Cin %% 32 == 0)");
+  ASW_CHECK_ARG(a.A2 == nullptr && a.mul == nullptr && a.resid == nullptr && a.ln_gamma == nullptr && a.stats == nullptr,
+                "mask_path: the encoder block takes A, weights and bias only");
+  ASW_CHECK_ARG(m.byp_k == 16 * KSB, "mask_path: bypass kernel padded to %d taps, %d given", 16 * KSB, m.byp_k);
+  ASW_CHECK_ARG(m.dec_taps > 0 && m.dec_taps <= 64 && m.ref_hop > 0 && m.ref_hop % 4 == 0 && m.ref_len > 0,
+                "mask_path: decoder taps 1..64, reference hop a multiple of 4 samples");
+  ASW_CHECK_ARG((reinterpret_cast<uintptr_t>(m.ref) & 15) == 0 && m.ref_batch_stride % 4 == 0,
+                "mask_path: reference rows must be 16-byte aligned");
+  a.precision = 1;
+  a.relu = 1;
+  constexpr size_t ring = (size_t)2 * 2 * BM * (BK + 8) * sizeof(_Float16);
+  constexpr size_t slab = (size_t)128 * (BN + 4) * sizeof(float);
+  constexpr size_t smem = ring > slab ? ring : slab;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  const void* kern = reinterpret_cast<const void*>(maskpath16p_kernel<BM, KSB>);
+  static asw::SmemAttr attr;                            // per device
+  if (int rc = attr.ensure(kern, smem)) return rc;
+  const long nrt = asw::cdiv(a.M_out, BM);
+  dim3 grid(((nrt * a.B + 7) / 8) * 8 * (a.N / BN), 1, 1);
+  std::string pn = "maskpath16p<256,256,32>";
+  if (asw::prof_detail()) {
+    char sh[64];
+    snprintf(sh, sizeof sh, "[B%d M%d N%d K%d s%d]", a.B, a.M_out, a.N, a.taps * a.Cin, a.stride);
+    pn += sh;
+  }
+  // mask encoder + bypass + decoder taps
+  asw::ProfScope prof(s, pn, 2.0 * a.B * (double)a.M_out * a.N * ((double)a.taps * a.Cin + m.byp_taps + m.dec_taps));
+  hipLaunchKernelGGL((maskpath16p_kernel<BM, KSB>), grid, dim3(512), smem, s, a, m);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
 }
 
 template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32>
@@ -1234,6 +1419,8 @@ extern "C" int asw_pack_fragments_f16(const float* Wt, int N, int K, uint16_t* h
   delete[] th;
   return rc;
 }
+
+extern "C" int asw_mask_path_f16x3(const asw_maskpath_args* args, void* stream) { return launch_mask_path(args, stream); }
 
 extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
   ASW_CHECK_ARG(args != nullptr, "convgemm: null args");

@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // per-frame tap products D[b][f][j] (computed by a GEMM), trim [trim_left : ...], keep
 // the last t samples (network.py:400-405), then y*std+mean (JointModel/network.py:96).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ D, int F, int ldd, int taps,
+// D may arrive as `nparts` partial tap tensors (the fused mask path writes one per 256-channel column
+// tile of the latent), part_stride floats apart; they are added in a fixed order.
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ D, int nparts, long part_stride,
+                                                          int F, int ldd, int taps,
                                                           int hop, int t, int lead, float bias,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ stdv, float* __restrict__ out) {
@@ -197,7 +200,11 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restric
   const float* Db = D + (long)b * F * ldd;
   for (int j = u % hop; j < taps; j += hop) {
     const int f = (u - j) / hop;
-    if (f >= 0 && f < F) s += Db[(long)f * ldd + j];
+    if (f >= 0 && f < F) {
+      float v = Db[(long)f * ldd + j];
+      for (int q = 1; q < nparts; ++q) v += Db[q * part_stride + (long)f * ldd + j];
+      s += v;
+    }
   }
   if (mean) s = s * stdv[b] + mean[b];
   out[(long)b * t + i] = s;
@@ -470,7 +477,14 @@ extern "C" int asw_attention(const float* qkv, int B, int L, int d, int nhead, f
 extern "C" int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int taps, int hop, int t,
                                       int trim_left, int trim_right, float bias, const float* mean, const float* std, float* out,
                                       void* stream) {
+  return asw_overlap_add_parts(D, 1, B, F, ldd, taps, hop, t, trim_left, trim_right, bias, mean, std, out, stream);
+}
+
+extern "C" int asw_overlap_add_parts(const float* D, int nparts, int B, int F, int ldd, int taps, int hop, int t,
+                                     int trim_left, int trim_right, float bias, const float* mean, const float* std, float* out,
+                                     void* stream) {
   ASW_CHECK_ARG(D && out, "overlap_add: null pointer");
+  ASW_CHECK_ARG(nparts >= 1 && nparts <= 64, "overlap_add: 1..64 partial tap tensors");
   ASW_CHECK_ARG(B > 0 && F > 0 && taps > 0 && taps <= ldd && hop > 0 && t > 0, "overlap_add: bad shape");
   const int kept = (F - 1) * hop + taps - trim_left - trim_right;
   ASW_CHECK_ARG(trim_left >= 0 && trim_right >= 0 && kept >= t, "overlap_add: %d samples after the trim, %d requested", kept, t);
@@ -478,8 +492,8 @@ extern "C" int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int
   ASW_CHECK_ARG((mean == nullptr) == (std == nullptr), "overlap_add: mean/std must both be given or both NULL");
   ASW_CHECK_ARG(B <= 65535, "overlap_add: batch too large");
   dim3 grid(asw::cdiv(t, 256), B);
-  hipLaunchKernelGGL(overlap_add_kernel, grid, dim3(256), 0, asw::as_stream(stream), D, F, ldd, taps, hop, t,
-                     lead, bias, mean, std, out);
+  hipLaunchKernelGGL(overlap_add_kernel, grid, dim3(256), 0, asw::as_stream(stream), D, nparts, (long)B * F * ldd, F, ldd,
+                     taps, hop, t, lead, bias, mean, std, out);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }

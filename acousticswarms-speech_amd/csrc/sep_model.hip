@@ -62,6 +62,7 @@ struct asw_sep {
   std::vector<ConfLayer> conf;
   std::vector<InterLayer> inter;
   WBuf byp_wt, mask_wt, dec_wt;
+  WBuf byp_wt48;                           // bypass kernel padded to 48 taps, fragment order (fused mask path)
   DevBuf byp_b, mask_b;
   float out_bias = 0.f;
   int byp_k = 0;
@@ -191,6 +192,13 @@ struct Plan {
   float *Y, *D, *ywave;
 };
 
+// The one-launch mask path (asw_mask_path_f16x3) applies in f16x3 mode when the shapes fit its tiles.
+bool fused_mask_path(const asw_sep* m) {
+  const asw_sep_config& c = m->cfg;
+  return m->precision == 1 && c.encoder_channels % 256 == 0 && c.channels % 32 == 0 && c.encoder_kernel_size <= 48 &&
+         c.encoder_stride % 4 == 0 && m->byp_wt48.fhi && m->dec_wt.fhi && m->mask_wt.fhi;
+}
+
 void layout(const asw_sep* m, int NB, int S, int T, Arena& a, Plan& pl) {
   const asw_sep_config& c = m->cfg;
   const int BS = NB * S;
@@ -234,8 +242,9 @@ void layout(const asw_sep* m, int NB, int S, int T, Arena& a, Plan& pl) {
   pl.raw2 = a.take<float>(rows * 2 * d);
   pl.f = a.take<float>(rows * c.ffw_dim);
   pl.pos = a.take<float>((2 * L - 1) * d);
-  pl.Y = a.take<float>((size_t)BS * pl.F * c.encoder_channels);
-  pl.D = a.take<float>((size_t)BS * pl.F * 64);
+  const bool fused = fused_mask_path(m);
+  pl.Y = fused ? nullptr : a.take<float>((size_t)BS * pl.F * c.encoder_channels);
+  pl.D = a.take<float>((size_t)(fused ? c.encoder_channels / 256 : 1) * BS * pl.F * 64);
   pl.ywave = a.take<float>((size_t)BS * T);
 }
 
@@ -378,6 +387,20 @@ int run_network(asw_sep* m, Plan& pl, const float* mean, const float* stdv, floa
   }
   // ---- mask path (:457-484): every speaker's mask gates the latent of the shared reference channel
   const int E = c.encoder_channels, EK = c.encoder_kernel_size, ES = c.encoder_stride;
+  if (fused_mask_path(m)) {
+    asw_maskpath_args f = {};
+    asw_convgemm_args& a = f.enc;
+    a.A = x; m->mask_wt.bind(a, 1); a.bias = m->mask_b.p;
+    a.B = B; a.M_out = pl.F; a.N = E; a.Cin = c.channels; a.taps = EK; a.stride = ES; a.dil = 1; a.pad = EK / 2;
+    a.a_row_stride = c.channels; a.a_batch_stride = (int64_t)pl.Tp * c.channels; a.a_len = a.a_batch_stride;
+    f.ref = pl.refn; f.ref_batch_stride = pl.RL; f.ref_len = pl.RL; f.ref_hop = ES;
+    f.byp_k = 48; f.byp_taps = EK; f.byp_shift = m->byp_wt48.shift; f.byp_hi = m->byp_wt48.fhi; f.byp_lo = m->byp_wt48.flo;
+    f.byp_bias = m->byp_b.p;
+    f.dec_hi = m->dec_wt.fhi; f.dec_lo = m->dec_wt.flo; f.dec_shift = m->dec_wt.shift; f.dec_taps = EK;
+    f.taps = pl.D;
+    if ((rc = asw_mask_path_f16x3(&f, s))) return rc;
+    return asw_overlap_add_parts(pl.D, E / 256, B, pl.F, 64, EK, EK / 2, pl.T, 9, 8, m->out_bias, mean, stdv, out_wave, s);
+  }
   {
     asw_convgemm_args a = {};
     a.A = pl.refn; m->byp_wt.bind(a, m->precision); a.bias = m->byp_b.p; a.out = pl.Y;
@@ -600,6 +623,12 @@ extern "C" int asw_sep_finalize(asw_sep* m) {
       for (int k = 0; k < EK; ++k) wt[(size_t)n * m->byp_k + k] = w[(size_t)n * EK + k];
     UP(m->byp_wt, wt);
     UP(m->byp_b, P(m, "reference_bypass.bias"));
+    if (E % 32 == 0 && EK <= 48) {
+      std::vector<float> w48((size_t)E * 48, 0.f);
+      for (int n = 0; n < E; ++n)
+        for (int k = 0; k < EK; ++k) w48[(size_t)n * 48 + k] = w[(size_t)n * EK + k];
+      if ((rc = m->byp_wt48.upload_gemm(w48, E, 48))) return rc;
+    }
   }
   if ((rc = m->mask_wt.upload_gemm(pack_conv(P(m, "mask_encoder.weight"), E, c.channels, EK, nullptr), E, c.channels * EK))) return rc;
   UP(m->mask_b, P(m, "mask_encoder.bias"));
@@ -608,7 +637,7 @@ extern "C" int asw_sep_finalize(asw_sep* m) {
     std::vector<float> wt((size_t)64 * E, 0.f);
     for (int j = 0; j < EK; ++j)
       for (int e = 0; e < E; ++e) wt[(size_t)j * E + e] = w[(size_t)e * EK + j];
-    UP(m->dec_wt, wt);
+    if ((rc = m->dec_wt.upload_gemm(wt, 64, E))) return rc;
     m->out_bias = P(m, "output_decoder.bias")[0];
   }
 #undef UP

@@ -53,6 +53,8 @@ struct asw_spot {
   std::vector<DecBlock> dec;
   std::vector<TfLayer> tf;
   WBuf byp_wt, mask_wt, dec_wt;
+  WBuf byp_wt48;                           // bypass kernel padded to 48 taps, fragment order (fused mask path)
+  bool fuse_mask = true;                   // f16x3: bypass + mask encoder + decoder taps in one launch
   DevBuf byp_b, mask_b;
   int precision = 0;                       // 0 = exact f32 MFMA, 1 = f16x3 split MFMA
   float out_bias = 0.f;
@@ -206,6 +208,13 @@ int get_gates(asw_spot* m, float w0, float w1, GateSet** out) {
   return ASW_OK;
 }
 
+// The one-launch mask path (asw_mask_path_f16x3) applies in f16x3 mode when the shapes fit its tiles.
+bool fused_mask_path(const asw_spot* m) {
+  const asw_spot_config& c = m->cfg;
+  return m->fuse_mask && m->precision == 1 && c.encoder_channels % 256 == 0 && c.channels % 32 == 0 &&
+         c.encoder_kernel_size <= 48 && c.encoder_stride % 4 == 0 && m->byp_wt48.fhi && m->dec_wt.fhi && m->mask_wt.fhi;
+}
+
 struct Plan {
   int B, T, Tp, F, RL, depth;
   std::vector<int> Tl;                     // length at level 0..depth
@@ -254,8 +263,10 @@ void layout(const asw_spot* m, int B, int T, Arena& a, Plan& pl) {
   pl.ff = a.take<float>((size_t)B * L * c.ffw_dim);
   pl.ha = a.take<float>((size_t)B * L * d);
   pl.hb = a.take<float>((size_t)B * L * d);
-  pl.Y = a.take<float>((size_t)B * pl.F * c.encoder_channels);
-  pl.D = a.take<float>((size_t)B * pl.F * 64);
+  const bool fused = fused_mask_path(m);
+  // fused mask path: no latent, one partial tap tensor per 256-channel column tile
+  pl.Y = fused ? nullptr : a.take<float>((size_t)B * pl.F * c.encoder_channels);
+  pl.D = a.take<float>((size_t)(fused ? c.encoder_channels / 256 : 1) * B * pl.F * 64);
   pl.ywave = a.take<float>((size_t)B * T);
   pl.escr = a.take<double>((size_t)B * (T + 1));
 }
@@ -337,6 +348,21 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
   }
   // ---- mask path (network.py:327-349,397-405)
   const int E = c.encoder_channels, EK = c.encoder_kernel_size, ES = c.encoder_stride;
+  if (fused_mask_path(m)) {
+    asw_maskpath_args f = {};
+    asw_convgemm_args& a = f.enc;
+    a.A = x; m->mask_wt.bind(a, 1); a.bias = m->mask_b.p;
+    a.B = B; a.M_out = pl.F; a.N = E; a.Cin = c.channels; a.taps = EK; a.stride = ES; a.dil = 1; a.pad = EK / 2;
+    a.a_row_stride = c.channels; a.a_batch_stride = (int64_t)pl.Tp * c.channels; a.a_len = a.a_batch_stride;
+    f.ref = pl.refn; f.ref_batch_stride = pl.RL; f.ref_len = pl.RL; f.ref_hop = ES;
+    f.byp_k = 48; f.byp_taps = EK; f.byp_shift = m->byp_wt48.shift; f.byp_hi = m->byp_wt48.fhi; f.byp_lo = m->byp_wt48.flo;
+    f.byp_bias = m->byp_b.p;
+    f.dec_hi = m->dec_wt.fhi; f.dec_lo = m->dec_wt.flo; f.dec_shift = m->dec_wt.shift; f.dec_taps = EK;
+    f.taps = pl.D;
+    if ((rc = asw_mask_path_f16x3(&f, s))) return rc;
+    m->taps.erase("latent");                                   // not materialised on this path
+    return asw_overlap_add_parts(pl.D, E / 256, B, pl.F, 64, EK, EK / 2, pl.T, 9, 8, m->out_bias, mean, stdv, out_wave, s);
+  }
   {
     asw_convgemm_args a = {};   // reference_bypass: rows of the padded reference channel, hop ES
     a.A = pl.refn; m->byp_wt.bind(a, m->precision); a.bias = m->byp_b.p; a.out = pl.Y;
@@ -510,6 +536,12 @@ extern "C" int asw_spot_finalize(asw_spot* m) {
       for (int k = 0; k < EK; ++k) wt[(size_t)n * m->byp_k + k] = w[(size_t)n * EK + k];
     UP(m->byp_wt, wt);
     UP(m->byp_b, P(m, "reference_bypass.bias"));
+    if (E % 32 == 0 && EK <= 48) {
+      std::vector<float> w48((size_t)E * 48, 0.f);
+      for (int n = 0; n < E; ++n)
+        for (int k = 0; k < EK; ++k) w48[(size_t)n * 48 + k] = w[(size_t)n * EK + k];
+      if ((rc = m->byp_wt48.upload_gemm(w48, E, 48))) return rc;
+    }
   }
   if ((rc = m->mask_wt.upload_gemm(pack_conv(P(m, "mask_encoder.weight"), E, c.channels, EK, nullptr), E, c.channels * EK))) return rc;
   UP(m->mask_b, P(m, "mask_encoder.bias"));
@@ -518,7 +550,7 @@ extern "C" int asw_spot_finalize(asw_spot* m) {
     std::vector<float> wt((size_t)64 * E, 0.f);
     for (int j = 0; j < EK; ++j)
       for (int e = 0; e < E; ++e) wt[(size_t)j * E + e] = w[(size_t)e * EK + j];
-    UP(m->dec_wt, wt);
+    if ((rc = m->dec_wt.upload_gemm(wt, 64, E))) return rc;
     m->out_bias = P(m, "output_decoder.bias")[0];
   }
 #undef UP
@@ -612,6 +644,12 @@ extern "C" int asw_spot_forward(asw_spot* m, const float* mix_norm, int B, int M
       return rc;
     if ((rc = run_network(m, pl, gs, nullptr, nullptr, out + (size_t)i0 * t, s))) return rc;
   }
+  return ASW_OK;
+}
+
+extern "C" int asw_spot_set_fused_mask(asw_spot* m, int on) {
+  ASW_CHECK_ARG(m, "set_fused_mask: null model handle");
+  m->fuse_mask = on != 0;
   return ASW_OK;
 }
 

@@ -124,6 +124,13 @@ class ConvGemmArgs(Structure):
                 ("Wt_lo", c_void_p), ("Wf_hi", c_void_p), ("Wf_lo", c_void_p), ("stats_stride", c_int32)]
 
 
+class MaskPathArgs(Structure):
+    _fields_ = [("enc", ConvGemmArgs), ("ref", c_void_p), ("ref_batch_stride", c_int64), ("ref_len", c_int64),
+                ("ref_hop", c_int32), ("byp_k", c_int32), ("byp_taps", c_int32), ("byp_shift", c_int32),
+                ("byp_hi", c_void_p), ("byp_lo", c_void_p), ("byp_bias", c_void_p), ("dec_hi", c_void_p),
+                ("dec_lo", c_void_p), ("dec_shift", c_int32), ("dec_taps", c_int32), ("taps", c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/asw_hip.h
 SIGNATURES = {
     "asw_last_error": (c_char_p, []),
@@ -142,6 +149,7 @@ SIGNATURES = {
     "asw_spot_shift_and_sep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_int, c_void_p]),
     "asw_spot_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p, c_void_p]),
+    "asw_spot_set_fused_mask": (c_int, [c_void_p, c_int]),
     "asw_spot_get_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]),
     "asw_sep_create": (c_int, [POINTER(SepConfigC), POINTER(c_void_p)]),
     "asw_sep_destroy": (None, [c_void_p]),
@@ -167,6 +175,7 @@ SIGNATURES = {
     "asw_pad_preproc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_long, c_void_p]),
     "asw_convgemm_f32": (c_int, [POINTER(ConvGemmArgs), c_void_p]),
+    "asw_mask_path_f16x3": (c_int, [POINTER(MaskPathArgs), c_void_p]),
     "asw_convgemm_stats_tiles": (c_int, [c_int, c_int]),
     "asw_f16x3_overflow_count": (c_int, [c_int, POINTER(c_int32)]),
     "asw_gn_glu": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
@@ -174,6 +183,8 @@ SIGNATURES = {
     "asw_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "asw_overlap_add_unnorm": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "asw_overlap_add_parts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "asw_energies": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asw_pair_sisdr": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "asw_center_rows": (c_int, [c_void_p, c_int, c_int, c_void_p]),

@@ -8,7 +8,7 @@ from ctypes import byref
 
 import torch
 
-from .native import ConvGemmArgs, check, current_stream, lib, ptr
+from .native import ConvGemmArgs, MaskPathArgs, check, current_stream, lib, ptr
 
 
 def _f32(t):
@@ -149,6 +149,48 @@ def overlap_add_unnorm(D, taps, hop, t, trim_left, trim_right, bias, mean=None, 
     check(lib().asw_overlap_add_unnorm(ptr(_f32(D)), B, F, ldd, taps, hop, t, trim_left, trim_right, float(bias),
                                        ptr(mean), ptr(std), ptr(out), current_stream()))
     return out
+
+
+def overlap_add_parts(Dp, taps, hop, t, trim_left, trim_right, bias, mean=None, std=None):
+    """Dp [nparts][B][F][ldd] partial tap products (mask_path) -> out [B][t]."""
+    nparts, B, F, ldd = Dp.shape
+    out = torch.empty((B, t), dtype=torch.float32, device=Dp.device)
+    check(lib().asw_overlap_add_parts(ptr(_f32(Dp)), nparts, B, F, ldd, taps, hop, t, trim_left, trim_right,
+                                      float(bias), ptr(mean), ptr(std), ptr(out), current_stream()))
+    return out
+
+
+def mask_path(x, ref, ref_hop, enc_w, enc_b, byp_w, byp_b, dec_w, frames, stride, pad):
+    """Fused mask path (asw_mask_path_f16x3).  x [B][Tp][C] channels-last activations, ref [B][RL] padded
+    reference rows (frame f reads ref[b][f*ref_hop + k]), enc_w [E][C][EK], byp_w [E][1][EKb], dec_w
+    [E][1][EKd] torch-layout weights.  Returns the partial tap products [E/256][B][frames][64]."""
+    B, Tp, C = x.shape
+    E, _, EK = enc_w.shape
+    dev = x.device
+    Wt = pack_conv_weight(enc_w).to(dev)
+    fh, fl, sh = pack_fragments_f16(Wt, E, EK * C)
+    wb = torch.zeros((E, 48), dtype=torch.float32)
+    wb[:, :byp_w.shape[-1]] = byp_w[:, 0].cpu()
+    bh, bl, bsh = pack_fragments_f16(wb.to(dev), E, 48)
+    wd = torch.zeros((64, E), dtype=torch.float32)
+    wd[:dec_w.shape[-1]] = dec_w[:, 0].t().cpu()
+    dh, dl, dsh = pack_fragments_f16(wd.to(dev), 64, E)
+    parts = torch.zeros((E // 256, B, frames, 64), dtype=torch.float32, device=dev)
+    m = MaskPathArgs()
+    a = m.enc
+    a.A, a.bias = _f32(x).data_ptr(), (_f32(enc_b).data_ptr() if enc_b is not None else None)
+    a.B, a.M_out, a.N, a.Cin, a.taps, a.stride, a.dil, a.pad = B, frames, E, C, EK, stride, 1, pad
+    a.a_row_stride, a.a_batch_stride, a.a_len = C, Tp * C, Tp * C
+    a.precision, a.w_shift, a.Wf_hi, a.Wf_lo = 1, sh, fh.data_ptr(), fl.data_ptr()
+    m.ref, m.ref_batch_stride, m.ref_len, m.ref_hop = _f32(ref).data_ptr(), ref.shape[1], ref.shape[1], ref_hop
+    m.byp_k, m.byp_taps, m.byp_shift = 48, byp_w.shape[-1], bsh
+    m.byp_hi, m.byp_lo = bh.data_ptr(), bl.data_ptr()
+    m.byp_bias = _f32(byp_b).data_ptr() if byp_b is not None else None
+    m.dec_hi, m.dec_lo, m.dec_shift, m.dec_taps = dh.data_ptr(), dl.data_ptr(), dsh, dec_w.shape[-1]
+    m.taps = parts.data_ptr()
+    check(lib().asw_mask_path_f16x3(byref(m), current_stream()))
+    torch.cuda.current_stream().synchronize()
+    return parts
 
 
 def energies(y, window=12000):

@@ -261,6 +261,13 @@ class SpotModel:
 
     __call__ = forward
 
+    def set_fused_mask(self, on: bool = True):
+        """f16x3 mode: run the mask path (bypass, mask encoder, product, decoder taps) as one launch
+        (default) or as three GEMMs (the "latent" tap exists only then)."""
+        self._need()
+        native.check(native.lib().asw_spot_set_fused_mask(self._h, int(bool(on))))
+        return self
+
     def get_tap(self, name: str, shape=None):
         """Intermediate activation of the last forward (channels-last), for parity tests."""
         import torch

@@ -114,9 +114,15 @@ int asw_spot_shift_and_sep(asw_spot* m, const float* mix, int M, int T,
 int asw_spot_forward(asw_spot* m, const float* mix_norm, int B, int M, int t,
                      const float* window_embedding_host, float* out, void* stream);
 
+/* f16x3 mode runs the mask path (reference_bypass, mask_encoder, product, output_decoder taps) as ONE
+ * launch (asw_mask_path_f16x3) when the shapes fit (encoder_channels % 256 == 0, channels % 32 == 0,
+ * kernel <= 48): the latent is then never written and the "latent" tap does not exist.  on = 0
+ * selects the three-GEMM path (default: on). */
+int asw_spot_set_fused_mask(asw_spot* m, int on);
+
 /* Debug/parity tap: copy an intermediate activation of the LAST forward to `dst`
  * (channels-last [B][T_l][C] float32).  names: "preproc", "enc0".., "bottleneck",
- * "dec0".., "latent".  Returns the element count through *numel (dst may be NULL). */
+ * "dec0".., "latent" (three-GEMM mask path only).  Returns the element count through *numel (dst may be NULL). */
 int asw_spot_get_tap(asw_spot* m, const char* name, float* dst, size_t capacity, size_t* numel,
                      void* stream);
 
@@ -284,6 +290,38 @@ typedef struct asw_convgemm_args {
  * K % 16 == 0; hi/lo: N*K uint16 each (host). */
 int asw_pack_fragments_f16(const float* Wt, int N, int K, uint16_t* hi, uint16_t* lo, int32_t* w_shift);
 int asw_convgemm_f32(const asw_convgemm_args* args, void* stream);
+/* The mask path of the spot / separation network in ONE launch (f16x3 arithmetic), replacing
+ * reference_bypass -> ReLU, mask_encoder -> ReLU, their product and the output_decoder tap products
+ * (SpeakerLocalization/network.py:327-349,397-405; SpeakerSeparation/network.py:385-416) without the
+ * E-channel latents ever being written:
+ *   taps[c][b][f][j] = sum_{e in column tile c} relu(enc(x)[b][f][e] + bias_e) * relu(byp(ref)[b][f][e] + byp_bias_e) * D[e][j]
+ * `enc` describes the mask_encoder GEMM exactly as for asw_convgemm_f32 (A, Wf_hi / Wf_lo fragment-order
+ * weights, w_shift, bias, B, M_out = frames, N = E, Cin, taps, stride, pad, a_*; out / mul / stats unused;
+ * N % 256 == 0, Cin % 32 == 0).  Frame f of item b reads the bypass window
+ * ref[b*ref_batch_stride + f*ref_hop + k], k < byp_k (zero beyond ref_len); byp_hi / byp_lo: bypass weights
+ * [E][byp_k = 48] (taps beyond byp_taps zero) packed by asw_pack_fragments_f16 (shift byp_shift); dec_hi /
+ * dec_lo: decoder weights Wt[64][E] (row j = tap j, rows >= dec_taps zero) packed likewise (dec_shift).
+ * Output: N/256 partial tap tensors [N/256][B][M_out][64] (columns < dec_taps written) to be summed by
+ * asw_overlap_add_parts. */
+typedef struct asw_maskpath_args {
+  asw_convgemm_args enc;
+  const float* ref;
+  int64_t ref_batch_stride;
+  int64_t ref_len;
+  int32_t ref_hop;
+  int32_t byp_k;          /* padded bypass kernel length (48) */
+  int32_t byp_taps;       /* true bypass kernel length (33), for the FLOP count only */
+  int32_t byp_shift;
+  const void* byp_hi;
+  const void* byp_lo;
+  const float* byp_bias;  /* [E] or NULL */
+  const void* dec_hi;
+  const void* dec_lo;
+  int32_t dec_shift;
+  int32_t dec_taps;       /* 33 */
+  float* taps;            /* [N/256][B][M_out][64] */
+} asw_maskpath_args;
+int asw_mask_path_f16x3(const asw_maskpath_args* args, void* stream);
 /* Host helper: split n fp32 weights into the fp16 hi/lo pair used by precision 1 with the
  * power-of-two pre-scale that keeps the lo parts out of the fp16 subnormal range; returns
  * the shift through *w_shift.  hi/lo: n uint16 each (host). */
@@ -317,6 +355,11 @@ int asw_attention(const float* qkv, int B, int L, int d, int nhead, float* ctx, 
 int asw_overlap_add_unnorm(const float* D, int B, int F, int ldd, int taps, int hop,
                            int t, int trim_left, int trim_right, float bias, const float* mean,
                            const float* std, float* out, void* stream);
+/* Same with the tap products given as `nparts` partial tensors [nparts][B][F][ldd] that are added
+ * first (asw_mask_path_f16x3 writes one per 256-channel column tile of the latent). */
+int asw_overlap_add_parts(const float* D, int nparts, int B, int F, int ldd, int taps, int hop,
+                          int t, int trim_left, int trim_right, float bias, const float* mean,
+                          const float* std, float* out, void* stream);
 
 /* Per-candidate energies: mean removal, power = sum x^2, power2 = max windowed RMS
  * (local_utils_3d.py:13-17,349-354).  scratch: [B][T+1] float64.  out [B][2] float64. */

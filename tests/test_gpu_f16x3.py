@@ -120,6 +120,40 @@ def test_shift_and_sep_full_f16x3_vs_reference_golden(golden):
     assert min(snr_db(y32[i], g["y_strict1"][i]) for i in range(5)) > 100.0
 
 
+def test_fused_mask_path_matches_three_gemm_path(golden):
+    """f16x3 runs the mask path as one launch by default (asw_mask_path_f16x3: no latent in memory); the
+    three-GEMM path stays selectable.  Both against the reference's own output (g4b) and against each
+    other; the "latent" tap exists on the three-GEMM path only; the fused path keeps the range guard."""
+    from acousticswarms_speech_amd import ops
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.scenes import make_scene
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    from acousticswarms_speech_amd.spot import SpotModel
+    g = golden("g4b_shift_and_sep_full")
+    m = _model(FULL, 5, batch=4)
+    mix = torch.from_numpy(make_scene(2, 3, 7, 6000).mix)
+    y_fused = m.shift_and_sep(mix, list(g["offsets"]), Strict=1)
+    with pytest.raises(RuntimeError):
+        m.get_tap("latent")
+    m.set_fused_mask(False)
+    y_three = m.shift_and_sep(mix, list(g["offsets"]), Strict=1)
+    assert m.get_tap("latent").numel() > 0
+    ref = g["y_strict1"]
+    per_f = [snr_db(y_fused[i], ref[i]) for i in range(ref.shape[0])]
+    per_t = [snr_db(y_three[i], ref[i]) for i in range(ref.shape[0])]
+    both = [snr_db(y_fused[i], y_three[i]) for i in range(ref.shape[0])]
+    _log(f"mask path fused {np.round(per_f, 1)} dB, three GEMMs {np.round(per_t, 1)} dB vs reference; "
+         f"fused vs three {np.round(both, 1)} dB")
+    assert min(per_f) > 80.0 and min(per_t) > 80.0 and min(both) > 90.0
+    sd = make_spot_state_dict(FULL, 5)
+    big = dict(sd)
+    big["mask_encoder.weight"] = sd["mask_encoder.weight"] * 3.0e3
+    big["reference_bypass.weight"] = sd["reference_bypass.weight"] * 3.0e3
+    ops.f16x3_overflow_count(reset=True)
+    SpotModel(FULL, big, batch_size=2, precision="f16x3").to("cuda").shift_and_sep(mix, list(g["offsets"])[:2], Strict=1)
+    assert ops.f16x3_overflow_count(reset=True) > 0
+
+
 def test_f16x3_range_guard_counts_saturating_activations():
     """The f16x3 mode splits activations to fp16 halves that saturate at +-65504.  The plain GEMM
     epilogue counts un-normalised outputs beyond that range (asw_f16x3_overflow_count): zero for

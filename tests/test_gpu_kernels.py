@@ -235,6 +235,39 @@ def test_mask_path(ops):
     assert rel < 3e-6
 
 
+@pytest.mark.parametrize("B,E,Tp,t", [(2, 256, 2048, 1900), (3, 512, 8192 + 16 * 37, 8000)])
+def test_mask_path_fused(ops, B, E, Tp, t):
+    """The same mask path in one launch (asw_mask_path_f16x3: bypass and decoder taps in the mask
+    encoder's epilogue, partial taps per 256-channel column tile) against torch fp32; ragged last row
+    tile, two column tiles."""
+    C, EK, ES = 64, 33, 16
+    x = _rand(B, C, Tp, seed=40)
+    ref = _rand(B, 1, Tp, seed=41)
+    wb, bb = _rand(E, 1, EK, seed=42, scale=0.2), _rand(E, seed=43, scale=0.1)
+    wm, bm = _rand(E, C, EK, seed=44, scale=1 / math.sqrt(C * EK)), _rand(E, seed=45, scale=0.1)
+    wd, bd = _rand(E, 1, EK, seed=46, scale=1 / math.sqrt(E)), 0.05
+    y = F.relu(F.conv1d(ref, wb, bb, stride=ES, padding=EK // 2))
+    mask = F.relu(F.conv1d(x, wm, bm, stride=ES, padding=EK // 2))
+    lat = y * mask
+    full = F.conv_transpose1d(lat, wd, torch.tensor([bd]), stride=EK // 2)
+    want = full[..., 9:-8][..., -t:][:, 0]
+    Fr = lat.shape[-1]
+    RL = EK // 2 + Tp + 64 + 64
+    refx = torch.zeros(B, RL)
+    refx[:, EK // 2:EK // 2 + Tp] = ref[:, 0]
+    xc = x.transpose(1, 2).contiguous().cuda()
+    parts = ops.mask_path(xc, refx.cuda(), ES, wm, bm.cuda(), wb, bb.cuda(), wd, Fr, ES, EK // 2)
+    assert parts.shape == (E // 256, B, Fr, 64)
+    taps_want = torch.einsum("bef,ej->bfj", lat, wd[:, 0])
+    rel, _ = _relerr(parts.sum(0)[..., :EK].cpu(), taps_want)
+    _log(f"fused taps rel={rel:.3e}")
+    assert rel < 3e-6
+    out = ops.overlap_add_parts(parts, EK, EK // 2, t, 9, 8, bd)
+    rel, mx = _relerr(out.cpu(), want)
+    _log(f"fused decode rel={rel:.3e} max={mx:.3e}")
+    assert rel < 3e-6
+
+
 def test_energies_and_sisdr(ops):
     from oracle import spot_ref
     rng = np.random.default_rng(5)
