@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 
 prefix, out_path = sys.argv[1], sys.argv[2]
-DOM = "convgemm16p_kernel<256, false, true, false, 32>"      # mask encoder on the pipelined wide-tile kernel
+DOM = "maskpath16p_kernel<256, 3>"      # the mask path in one launch (bypass + mask encoder + decoder taps)
 
 
 def short(name):
@@ -33,15 +33,17 @@ with open(os.path.join(prefix, "bench_kernel_stats.csv")) as f:
     for r in csv.DictReader(f):
         stats[short(r["Name"])] = (float(r["AverageNs"]), int(r["Calls"]), float(r["Percentage"]))
 B, F, K, E, C = 256, 3008, 2112, 2048, 64
-alg = {"activation_read": B * 48128 * C * 4, "weights_read": E * K * 4, "bypass_latent_read": B * F * E * 4,
-       "masked_latent_write": B * F * E * 4}
+# the latents never leave the chip: decoder-block output read once, weights (fp16 hi + lo of the mask encoder, the
+# 48-tap bypass and the 64-row decoder matrix), the padded reference channel, 8 partial tap tensors of 33 columns
+alg = {"activation_read": B * 48128 * C * 4, "weights_read": E * (K + 48 + 64) * 4, "reference_read": B * (48128 + 144) * 4,
+       "partial_taps_write": (E // 256) * B * F * 33 * 4}
 alg_total = sum(alg.values())
 fr, fn = fetch[DOM]
 wr, _ = write[DOM]
 rec = {
-    "_comment": "HBM / fabric traffic of the dominant kernel of `python bench.py` (mask encoder, internal batch 256, T=48000), "
+    "_comment": "HBM / fabric traffic of the dominant kernel of `python bench.py` (fused mask path, internal batch 256, T=48000), "
                 "from separate rocprofv3 --pmc passes over that very command; per-launch means.",
-    "kernel": "convgemm16pm<256,256,32,plain>", "rocprof_name": DOM, "batch": B, "dispatches_averaged": fn,
+    "kernel": "maskpath16p<256,256,32>", "rocprof_name": DOM, "batch": B, "dispatches_averaged": fn,
     "FETCH_SIZE_KB_raw": fr, "WRITE_SIZE_KB": wr,
     "read_bytes_corrected_2x": int(fr * 1024 * 2), "write_bytes": int(wr * 1024),
     "corrected_bytes_per_launch": int(fr * 1024 * 2 + wr * 1024),
