@@ -258,3 +258,24 @@ def ptr(t):
 def current_stream():
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_device(a, device):
+    """Small host array -> device tensor through page-locked memory (no blocking copy call)."""
+    import torch
+    src = torch.from_numpy(a)
+    host = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+    host.copy_(src)
+    return host.to(device, non_blocking=True)
+
+
+def to_host(t):
+    """Device tensor -> numpy array backed by page-locked memory from torch's caching host allocator: the
+    [N, T] results of the reference-compatible calls (136 MB for one fine stage) cross PCIe at DMA rate and
+    the runtime has nothing to pin or un-pin per call."""
+    import torch
+    if not t.is_cuda:
+        return t.numpy()
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t)
+    return host.numpy()

@@ -149,8 +149,8 @@ class SepModel:
         if offs.shape[0] == 0:
             return np.empty((0, mix.shape[-1]), dtype=np.float32)
         mix_d = mix.to(self.device, dtype=torch.float32).contiguous()
-        off_d = torch.from_numpy(offs).to(self.device)
-        return self.infer_device(mix_d, off_d).cpu().numpy()
+        off_d = native.to_device(offs, self.device)
+        return native.to_host(self.infer_device(mix_d, off_d))
 
     def forward(self, mix, num_speakers):
         """Network.forward (:418-490): mix [B, S*M, t] already normalised, num_speakers [B,1]

@@ -172,7 +172,7 @@ class SpotModel:
         mix_d = mix.to(self.device, dtype=torch.float32).contiguous()
         off_d = torch.from_numpy(offs).to(self.device)
         wave, _ = self.shift_and_sep_device(mix_d, off_d, Strict, want_wave=True)
-        return wave.cpu().numpy()
+        return native.to_host(wave)
 
     def shift_and_score(self, input_channels, patch_list, Strict: int = 0, window: int = 12000,
                         keep_waveforms: bool = True) -> np.ndarray:
