@@ -13,6 +13,8 @@ from .search import (INIT_WIDTH, SPOT_POWER_THRESHOLD2, USE_RELATIVE_SPOT_POWER,
                      search_area)
 from .srp import SRPPhat
 
+FINE_CHUNK_EDGES = (0.0, 0.07, 0.40, 0.73, 0.93, 1.0)      # pipelined fine stage, see _fine_stage_pipelined
+
 # sep/helpers/constants.py:24-27
 BIN0, BIN1, N_FFT = 2, 200, 2048
 FREQ_BINS = np.arange(BIN0, BIN1)
@@ -285,8 +287,13 @@ class MicArray(object):
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=dev)
         side, main = self._side_stream, torch.cuda.current_stream(dev)
-        n_chunks = 3                                   # 4-6 chunks measured the same (240-244 ms end to end)
-        edges = [round(n_groups * k / n_chunks) for k in range(n_chunks + 1)]
+        # Chunk edges (fractions of the coarse patches).  Only two pieces of host work cannot hide behind
+        # the GPU: the subdivision of the first chunk and the clustering of the last one -- so those two
+        # chunks are small (about 1/15 of the patches each) and the middle ones large enough to keep the
+        # internal batches full.  (Bench scene, 710 candidates, same box: three equal chunks 361 ms; these
+        # edges 340; [0, .1, .5, .9, 1] 346; [0, .13, .5, .87, 1] 349; seven chunks 345.)
+        edges = sorted(set(min(n_groups, max(0, round(n_groups * f))) for f in FINE_CHUNK_EDGES) | {0, n_groups})
+        n_chunks = len(edges) - 1
         output_pair, inflight = [], None
 
         def finish(job):
@@ -346,29 +353,39 @@ class MicArray(object):
             seg_dev, _ = scorer.segment_sisdr(waves, seg_all)
         clusters = {}
         wrong = []
+        centres = [c[0].center_pos() for c in cands]
+        win_dev = None
+        if seg_dev is not None:
+            # check_sisnr_win of every ordered pair at once (entries beyond a candidate's own segment
+            # count are NaN and compare false, like the slice [:len(segs)] of the per-pair form)
+            with np.errstate(invalid="ignore"):
+                win_dev = np.any(seg_dev > -2, axis=2) & ~np.any(seg_dev < -7, axis=2)
         for i, cand in enumerate(cands):
-            centre1, audio1, power1, big_label = cand[0].center_pos(), cand[1], cand[2], cand[-1]
+            centre1, audio1, power1, big_label = centres[i], cand[1], cand[2], cand[-1]
             segs = seg_all[i]
             if len(segs) == 0:
                 print("discard because no invalid split!!!")
                 continue
             unique, belong = True, -1
-            seg_tab = []
+            seg_tab, seen = [], []
             for head in clusters:
                 h = clusters[head][0]
-                audio2, centre2 = cands[h][1], cands[h][0].center_pos()
+                audio2, centre2 = cands[h][1], centres[h]
                 if full_dev is not None:
-                    sim = full_dev[i, h]
-                    per_seg = list(seg_dev[i, h, :len(segs)])
+                    sim, win = full_dev[i, h], win_dev[i, h]
+                    seen.append(h)
                 else:
                     sim = si_sdr(audio1, audio2)
                     per_seg = split_wise_sisdr(audio1, audio2, segs)
-                seg_tab.append(per_seg)
+                    win = check_sisnr_win(per_seg)
+                    seg_tab.append(per_seg)
                 dis = np.linalg.norm(centre1[:2] - centre2[:2])
-                if sim > -1 or check_sisnr_win(per_seg) or dis < 0.45:      # (:401,458)
+                if sim > -1 or win or dis < 0.45:      # (:401,458)
                     clusters[h].append(i)
                     unique, belong = False, head
                     break
+            if seen:
+                seg_tab = seg_dev[i, seen, :len(segs)]
             if len(seg_tab) != 0:
                 best = np.amax(np.array(seg_tab), axis=0)
                 if check_sisnr_win(best, SISNR_THRESHOLD=-1, SISNR_THRESHOLD2=-5):
