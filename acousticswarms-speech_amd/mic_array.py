@@ -360,6 +360,18 @@ class MicArray(object):
             # count are NaN and compare false, like the slice [:len(segs)] of the per-pair form)
             with np.errstate(invalid="ignore"):
                 win_dev = np.any(seg_dev > -2, axis=2) & ~np.any(seg_dev < -7, axis=2)
+        near = None
+        if win_dev is not None and all(c is not None for c in centres):
+            # dis < 0.45 for every pair; entries within rounding of the threshold are settled by the very
+            # call the per-pair form makes
+            xy = np.array([c[:2] for c in centres], dtype=np.float64)
+            d = xy[:, None, :] - xy[None, :, :]
+            dist = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1])
+            near = dist < 0.45
+            for a, b in zip(*np.nonzero(np.abs(dist - 0.45) < 1e-9)):
+                near[a, b] = np.linalg.norm(centres[a][:2] - centres[b][:2]) < 0.45
+            merge = (full_dev > -1) | win_dev | near             # (:401,458) for every ordered pair
+        heads = []                                               # cluster heads in creation order
         for i, cand in enumerate(cands):
             centre1, audio1, power1, big_label = centres[i], cand[1], cand[2], cand[-1]
             segs = seg_all[i]
@@ -368,22 +380,27 @@ class MicArray(object):
                 continue
             unique, belong = True, -1
             seg_tab, seen = [], []
-            for head in clusters:
-                h = clusters[head][0]
-                audio2, centre2 = cands[h][1], centres[h]
-                if full_dev is not None:
-                    sim, win = full_dev[i, h], win_dev[i, h]
-                    seen.append(h)
+            if near is not None:
+                hit = np.flatnonzero(merge[i, heads]) if heads else np.empty(0, dtype=np.int64)
+                if hit.size:                                     # first head in creation order wins
+                    belong = heads[int(hit[0])]
+                    clusters[belong].append(i)
+                    unique = False
+                    seen = heads[:int(hit[0]) + 1]
                 else:
+                    seen = list(heads)
+            else:
+                for head in clusters:
+                    h = clusters[head][0]
+                    audio2, centre2 = cands[h][1], centres[h]
                     sim = si_sdr(audio1, audio2)
                     per_seg = split_wise_sisdr(audio1, audio2, segs)
-                    win = check_sisnr_win(per_seg)
                     seg_tab.append(per_seg)
-                dis = np.linalg.norm(centre1[:2] - centre2[:2])
-                if sim > -1 or win or dis < 0.45:      # (:401,458)
-                    clusters[h].append(i)
-                    unique, belong = False, head
-                    break
+                    dis = np.linalg.norm(centre1[:2] - centre2[:2])
+                    if sim > -1 or check_sisnr_win(per_seg) or dis < 0.45:      # (:401,458)
+                        clusters[h].append(i)
+                        unique, belong = False, head
+                        break
             if seen:
                 seg_tab = seg_dev[i, seen, :len(segs)]
             if len(seg_tab) != 0:
@@ -392,6 +409,7 @@ class MicArray(object):
                     unique = False
             if unique:
                 clusters[i] = [i]
+                heads.append(i)
             elif big_label >= 0 and sample_gt is not None and belong >= 0:
                 h = clusters[belong][0]
                 if cands[h][-1] == -1:
