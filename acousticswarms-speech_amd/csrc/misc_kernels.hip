@@ -270,83 +270,117 @@ __global__ __launch_bounds__(1024) void energy_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// SI-SDR of every ordered pair (sep/helpers/eval_utils.py:11-39): block (i=est, j=ref).
-// pass 1: <s,s>, <s,e>; pass 2: |a s|^2, |e - a s|^2 with the reference's float32
-// element arithmetic and double accumulation.
+// SI-SDR of every ordered pair (sep/helpers/eval_utils.py:11-39), (i = estimate, j = reference):
+//   a = <s,e>/<s,s>;  10 log10(|a s|^2 / (|e - a s|^2 + 1e-8)),  |e - a s|^2 = <e,e> - <s,e>^2/<s,s>.
+// The three inner products are exact float32 products accumulated in double (a float32 x float32
+// product is exact in double), so the Gram form loses nothing against the reference's element-wise
+// float32 residual up to > 100 dB; the residual is clamped at 0 before MIN_ERR is added.
+// A workgroup owns a 16 x 16 block of pairs and streams T in 64-sample chunks through LDS: every
+// sample of the 32 rows is fetched once per block instead of once per pair (n = 301 waveforms of the
+// bench scene: 6.2 -> 0.3 ms).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pair_sisdr_kernel(const float* __restrict__ y, int T,
+__device__ __forceinline__ double sisdr_from_products(double ee, double ss, double es) {
+  const double sss = es * es / ss;
+  double snn = ee - sss;
+  snn = (snn > 0.0 ? snn : 0.0) + 1e-8;
+  return 10.0 * log10(sss / snn);
+}
+
+__global__ __launch_bounds__(256) void pair_sisdr_kernel(const float* __restrict__ y, int n, int T,
                                                          double* __restrict__ out) {
-  __shared__ double red[4][2];
-  const int i = blockIdx.x, j = blockIdx.y, n = gridDim.x;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const float* e = y + (long)i * T;
-  const float* s = y + (long)j * T;
-  double a0 = 0, a1 = 0;
-  for (int t = tid; t < T; t += 256) { a0 += (double)(s[t] * s[t]); a1 += (double)(s[t] * e[t]); }
-  a0 = wave_sum_d(a0); a1 = wave_sum_d(a1);
-  if (lane == 0) { red[wid][0] = a0; red[wid][1] = a1; }
-  __syncthreads();
-  const float rss = (float)(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-  const float rse = (float)(red[0][1] + red[1][1] + red[2][1] + red[3][1]);
-  const float a = rse / rss;
-  __syncthreads();
-  double b0 = 0, b1 = 0;
-  for (int t = tid; t < T; t += 256) {
-    const float tr = a * s[t];
-    const float rs = e[t] - tr;
-    b0 += (double)(tr * tr);
-    b1 += (double)(rs * rs);
+  constexpr int KC = 64;
+  __shared__ float E[16][KC + 1], S[16][KC + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+  double ee = 0, ss = 0, es = 0;
+  float pe[4], ps[4];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int idx = tid + 256 * m, r = idx >> 6, c = idx & 63;
+      const bool okt = t0 + c < T;
+      pe[m] = (okt && i0 + r < n) ? y[(long)(i0 + r) * T + t0 + c] : 0.f;
+      ps[m] = (okt && j0 + r < n) ? y[(long)(j0 + r) * T + t0 + c] : 0.f;
+    }
+  };
+  fetch(0);
+  for (int t0 = 0; t0 < T; t0 += KC) {
+    __syncthreads();                                   // previous chunk consumed
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int idx = tid + 256 * m, r = idx >> 6, c = idx & 63;
+      E[r][c] = pe[m];
+      S[r][c] = ps[m];
+    }
+    __syncthreads();
+    if (t0 + KC < T) fetch(t0 + KC);                   // in flight under the products of this chunk
+#pragma unroll 16
+    for (int k = 0; k < KC; ++k) {
+      const double e = (double)E[ty][k], sv = (double)S[tx][k];
+      ee += e * e;
+      ss += sv * sv;
+      es += e * sv;
+    }
   }
-  b0 = wave_sum_d(b0); b1 = wave_sum_d(b1);
-  if (lane == 0) { red[wid][0] = b0; red[wid][1] = b1; }
-  __syncthreads();
-  if (tid == 0) {
-    const double sss = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-    const double snn = red[0][1] + red[1][1] + red[2][1] + red[3][1] + 1e-8;
-    out[(long)i * n + j] = 10.0 * log10(sss / snn);
-  }
+  const int i = i0 + ty, j = j0 + tx;
+  if (i < n && j < n) out[(long)i * n + j] = sisdr_from_products(ee, ss, es);
 }
 
 // Segment-wise SI-SDR (split_wise_sisdr, sep/helpers/eval_utils.py:73-82; call site
 // Mic_Array.py:432-458): for every ordered pair (i = estimate, j = reference) the SI-SDR over
-// each voiced segment [a,b) of waveform i.  Block (i, j) walks i's segments; per segment the
-// same two passes and float32 element arithmetic as pair_sisdr_kernel.
-__global__ __launch_bounds__(256) void seg_sisdr_kernel(const float* __restrict__ y, int T, const int* __restrict__ seg,
-                                                        const int* __restrict__ cnt, int kmax,
+// each voiced segment [a,b) of waveform i, same Gram form.  A workgroup owns estimate i and 64
+// references: thread (j, q) accumulates the products of samples q*16 .. q*16+15 of every 64-sample
+// chunk (references through an LDS tile, one coalesced fetch per chunk, the next chunk prefetched
+// into registers), the four partial sums meet in LDS at the end of a segment.
+__global__ __launch_bounds__(256) void seg_sisdr_kernel(const float* __restrict__ y, int n, int T,
+                                                        const int* __restrict__ seg, const int* __restrict__ cnt, int kmax,
                                                         double* __restrict__ out) {
-  __shared__ double red[4][2];
-  const int i = blockIdx.x, j = blockIdx.y, n = gridDim.x;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int KC = 64;
+  __shared__ float Ev[KC], S[64][KC + 1];
+  __shared__ double red[3][4][64];
+  const int i = blockIdx.x, j0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, jl = tid & 63, q = tid >> 6;
   const int nseg = cnt[i];
+  const float* __restrict__ ei = y + (long)i * T;
+  float ps[16], pe = 0.f;
   for (int k = 0; k < nseg; ++k) {
-    const int a0i = seg[((long)i * kmax + k) * 2], b0i = seg[((long)i * kmax + k) * 2 + 1];
-    const float* e = y + (long)i * T + a0i;
-    const float* s = y + (long)j * T + a0i;
-    const int len = b0i - a0i;
-    double a0 = 0, a1 = 0;
-    for (int t = tid; t < len; t += 256) { a0 += (double)(s[t] * s[t]); a1 += (double)(s[t] * e[t]); }
-    a0 = wave_sum_d(a0); a1 = wave_sum_d(a1);
-    __syncthreads();                                   // red[] of the previous segment consumed
-    if (lane == 0) { red[wid][0] = a0; red[wid][1] = a1; }
-    __syncthreads();
-    const float rss = (float)(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-    const float rse = (float)(red[0][1] + red[1][1] + red[2][1] + red[3][1]);
-    const float a = rse / rss;
-    __syncthreads();
-    double b0 = 0, b1 = 0;
-    for (int t = tid; t < len; t += 256) {
-      const float tr = a * s[t];
-      const float rs = e[t] - tr;
-      b0 += (double)(tr * tr);
-      b1 += (double)(rs * rs);
+    const int a = seg[((long)i * kmax + k) * 2], b = seg[((long)i * kmax + k) * 2 + 1];
+    double ee = 0, ss = 0, es = 0;
+    auto fetch = [&](int t0) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int idx = tid + 256 * m, r = idx >> 6, c = idx & 63;
+        ps[m] = (t0 + c < b && j0 + r < n) ? y[(long)(j0 + r) * T + t0 + c] : 0.f;
+      }
+      if (tid < KC) pe = (t0 + tid < b) ? ei[t0 + tid] : 0.f;
+    };
+    fetch(a);
+    for (int t0 = a; t0 < b; t0 += KC) {
+      __syncthreads();                                 // previous chunk (and the previous segment's red[]) consumed
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int idx = tid + 256 * m, r = idx >> 6, c = idx & 63;
+        S[r][c] = ps[m];
+      }
+      if (tid < KC) Ev[tid] = pe;
+      __syncthreads();
+      if (t0 + KC < b) fetch(t0 + KC);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double e = (double)Ev[q * 16 + c], sv = (double)S[jl][q * 16 + c];
+        ee += e * e;
+        ss += sv * sv;
+        es += e * sv;
+      }
     }
-    b0 = wave_sum_d(b0); b1 = wave_sum_d(b1);
-    if (lane == 0) { red[wid][0] = b0; red[wid][1] = b1; }
     __syncthreads();
-    if (tid == 0) {
-      const double sss = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-      const double snn = red[0][1] + red[1][1] + red[2][1] + red[3][1] + 1e-8;
-      out[((long)i * n + j) * kmax + k] = 10.0 * log10(sss / snn);
+    red[0][q][jl] = ee; red[1][q][jl] = ss; red[2][q][jl] = es;
+    __syncthreads();
+    if (q == 0 && j0 + jl < n) {
+      const double fe = (red[0][0][jl] + red[0][1][jl]) + (red[0][2][jl] + red[0][3][jl]);
+      const double fs = (red[1][0][jl] + red[1][1][jl]) + (red[1][2][jl] + red[1][3][jl]);
+      const double fx = (red[2][0][jl] + red[2][1][jl]) + (red[2][2][jl] + red[2][3][jl]);
+      out[((long)i * n + j0 + jl) * kmax + k] = sisdr_from_products(fe, fs, fx);
     }
   }
 }
@@ -511,8 +545,8 @@ extern "C" int asw_segment_sisdr(const float* y, int n, int T, const int32_t* se
                                  int kmax, double* out, void* stream) {
   ASW_CHECK_ARG(y && segments && seg_count && out, "segment_sisdr: null pointer");
   ASW_CHECK_ARG(n > 0 && n <= 65535 && T > 0 && kmax > 0, "segment_sisdr: bad shape");
-  hipLaunchKernelGGL(seg_sisdr_kernel, dim3(n, n), dim3(256), 0, asw::as_stream(stream), y, T, segments, seg_count,
-                     kmax, out);
+  hipLaunchKernelGGL(seg_sisdr_kernel, dim3(n, asw::cdiv(n, 64)), dim3(256), 0, asw::as_stream(stream), y, n, T, segments,
+                     seg_count, kmax, out);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }
@@ -520,7 +554,8 @@ extern "C" int asw_segment_sisdr(const float* y, int n, int T, const int32_t* se
 extern "C" int asw_pair_sisdr(const float* y, int n, int T, double* out, void* stream) {
   ASW_CHECK_ARG(y && out, "pair_sisdr: null pointer");
   ASW_CHECK_ARG(n > 0 && n <= 65535 && T > 0, "pair_sisdr: bad shape");
-  hipLaunchKernelGGL(pair_sisdr_kernel, dim3(n, n), dim3(256), 0, asw::as_stream(stream), y, T, out);
+  hipLaunchKernelGGL(pair_sisdr_kernel, dim3(asw::cdiv(n, 16), asw::cdiv(n, 16)), dim3(256), 0, asw::as_stream(stream), y, n, T,
+                     out);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }

@@ -88,6 +88,7 @@ class MicArray(object):
         self.big_spotforming_times = 0
         self._device_scorer = None      # set by the fine stage when the spot model offers the GPU SI-SDR kernels
         self._seg_cache = {}
+        self._dev_cache = {}
         # decision trace of the latest search (cheap bookkeeping, used by the precision flip-rate and
         # parity tests): coarse kept indices, per coarse patch {head: members} of the fine-stage
         # clustering, and the global clusters as lists of "g_head" names
@@ -189,12 +190,16 @@ class MicArray(object):
                 sim["m"] = spot_model.pair_sisdr(waves_g)
             return sim["m"][k, h]
 
+        kept = {}
+
         def audio_of(heads):
-            return waves_g[heads].cpu().numpy()
+            kept["rows"] = waves_g[heads]
+            return kept["rows"].cpu().numpy()
         out = self._cluster_group(g, big, patches, list(energies_g[:, 0]), list(energies_g[:, 1]), area, centre,
                                   T_len, thr_new, sample_gt, sim_of, audio_of)
-        for pair in out:                   # the global clustering needs these; here they hide behind the GPU
+        for n, pair in enumerate(out):     # the global clustering needs these; here they hide behind the GPU
             self._seg_cache[id(pair[1])] = (pair[1], split_wav(pair[1]))
+            self._dev_cache[id(pair[1])] = (pair[1], kept["rows"][n])      # the same waveform, still on the GPU
         return out
 
     def Spotform_Small_Patch_Parallel(self, mix_data, candidate_finished, spot_model, sample_gt=None,
@@ -208,6 +213,7 @@ class MicArray(object):
         n_groups = len(candidate_finished)
         self.spotforming_times = 0
         self._seg_cache = {}               # id(waveform) -> (waveform, voiced segments), filled by the resident path
+        self._dev_cache = {}               # id(waveform) -> (waveform, its device row)
         if resident and not sharded and n_groups >= 3 and getattr(spot_model, "device", None) is not None:
             return self._fine_stage_pipelined(mix_data, candidate_finished, spot_model, sample_gt, thr_new)
 
@@ -347,8 +353,12 @@ class MicArray(object):
         full_dev = seg_dev = None
         if scorer is not None and len(cands) > 1:
             import torch
-            waves = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(c[1], dtype=np.float32) for c in cands])))
-            waves = waves.to(scorer.device if getattr(scorer, "device", None) is not None else "cuda")
+            dev_rows = [getattr(self, "_dev_cache", {}).get(id(c[1])) for c in cands]
+            if all(r is not None and r[0] is c[1] for r, c in zip(dev_rows, cands)):
+                waves = torch.stack([r[1] for r in dev_rows])         # the fine stage left every row on the GPU
+            else:
+                waves = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(c[1], dtype=np.float32) for c in cands])))
+                waves = waves.to(scorer.device if getattr(scorer, "device", None) is not None else "cuda")
             full_dev = scorer.pair_sisdr(waves)
             seg_dev, _ = scorer.segment_sisdr(waves, seg_all)
         clusters = {}
