@@ -47,6 +47,19 @@ struct SmemAttr {
 };
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+#ifdef __HIPCC__
+// GroupNorm(2) + GLU of one (value, gate) pair: (a - m0) r0 ga + ba, gated by the sigmoid of the normalised
+// gate.  One definition with every rounding spelled out, because two kernels apply it (gn_glu_kernel and the
+// residual layer that normalises while it loads) and must agree to the bit whatever the compiler would
+// contract around them.
+__device__ __forceinline__ float gn_glu_value(float a, float g, float m0, float r0, float m1, float r1, float ga, float ba,
+                                              float gg, float bg) {
+  const float av = __fmaf_rn(__fmul_rn(__fsub_rn(a, m0), r0), ga, ba);
+  const float gv = __fmaf_rn(__fmul_rn(__fsub_rn(g, m1), r1), gg, bg);
+  return __fdiv_rn(av, __fadd_rn(1.0f, expf(-gv)));
+}
+#endif
+
 }  // namespace asw
 
 // ---- optional in-library launch profiler (HIP events on the launch stream) -----------

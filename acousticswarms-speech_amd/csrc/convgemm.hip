@@ -987,11 +987,12 @@ struct ResRows {
   }
 };
 
-template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1)>
+template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1), bool GLU = false>
 __global__ __launch_bounds__(64 * WM * WN)
 __attribute__((amdgpu_waves_per_eu(C == 64 ? 4 : WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 ? 2 : (C == 128 ? ASW_RES128_WAVES : 3)) : (C == 64 && WM * WN == 4 ? 4 : 1)))))
 void resconv16_kernel(const asw_convgemm_args p) {
   static_assert(QD == 2 || QD == 4, "B prefetch depth in k-steps");
+  static_assert(!GLU || (C == 64 && PH == 1 && !POLY), "GroupNorm + GLU on load: contiguous C = 64 tiles only");
   static_assert(WM * WN == 2 || WM * WN == 4 || WM * WN == 8, "2, 4 or 8 waves per workgroup");
   constexpr int NTHR = 64 * WM * WN, SROWS = NTHR / 16;   // staging: 16 threads per row
   constexpr int TM = BM / WM / 32, TN = C / WN / 32;
@@ -1015,7 +1016,9 @@ void resconv16_kernel(const asw_convgemm_args p) {
   const int RJ = BMJ + (!POLY ? (taps - 1) * dil : taps - 1);      // image rows per phase
   const int R = PH * RJ;
   const int tapstep = !POLY ? dil : 1;
-  const __amdgpu_buffer_rsrc_t rX = act_rsrc(p.A + (long)b * p.a_batch_stride, (long)T * C);
+  // GLU: the input row g is GLU(GroupNorm(raw row g)), raw = [T][value half 64 | gate half 64]
+  const __amdgpu_buffer_rsrc_t rX = GLU ? act_rsrc(p.glu_raw + (long)b * T * 2 * C, (long)T * 2 * C)
+                                        : act_rsrc(p.A + (long)b * p.a_batch_stride, (long)T * C);
   const half8* __restrict__ Wh = reinterpret_cast<const half8*>(p.Wf_hi);
   const half8* __restrict__ Wl = reinterpret_cast<const half8*>(p.Wf_lo);
 
@@ -1036,6 +1039,15 @@ void resconv16_kernel(const asw_convgemm_args p) {
   }
   const int nt0 = wn * TN;                            // first N fragment of this wave
 
+  float gm0 = 0.f, gr0 = 0.f, gm1 = 0.f, gr1 = 0.f;
+  float4 gga, gba, ggg, gbg;
+  if (GLU) {
+    gm0 = p.glu_mr[b * 4 + 0]; gr0 = p.glu_mr[b * 4 + 1]; gm1 = p.glu_mr[b * 4 + 2]; gr1 = p.glu_mr[b * 4 + 3];
+    gga = *reinterpret_cast<const float4*>(p.glu_gamma + sc4 * 4);
+    gba = *reinterpret_cast<const float4*>(p.glu_beta + sc4 * 4);
+    ggg = *reinterpret_cast<const float4*>(p.glu_gamma + C + sc4 * 4);
+    gbg = *reinterpret_cast<const float4*>(p.glu_beta + C + sc4 * 4);
+  }
   ASW_PHASE_MARK(t_begin);
 #ifdef ASW_PHASE_TIMING
   unsigned long long t_stage = 0, t_loop = 0;
@@ -1046,6 +1058,8 @@ void resconv16_kernel(const asw_convgemm_args p) {
     // ---- stage + split the image of this channel slice (8 rows per thread in flight)
     for (int r0 = 0; r0 < R; r0 += SROWS * 8) {
       float4 buf[8];
+      float4 gate[GLU ? 8 : 1];
+      bool okr[GLU ? 8 : 1];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int row = r0 + u * SROWS + srow;
@@ -1059,7 +1073,28 @@ void resconv16_kernel(const asw_convgemm_args p) {
           ok = ok && ph < dil && (jb * BMJ + row % RJ - (taps - 1) / 2) >= 0;
         }
         ok = ok && g >= 0 && g < T;
-        buf[u] = act_load4(rX, (long)g * C + cc * 64 + sc4 * 4, ok);
+        if (GLU) {
+          buf[u] = act_load4(rX, (long)g * 2 * C + sc4 * 4, ok);
+          gate[u] = act_load4(rX, (long)g * 2 * C + C + sc4 * 4, ok);
+          okr[u] = ok;
+        } else {
+          buf[u] = act_load4(rX, (long)g * C + cc * 64 + sc4 * 4, ok);
+        }
+      }
+      if (GLU) {
+        // the arithmetic of gn_glu_kernel, expression for expression; rows outside the sequence stay zero
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float4 o;
+#define ASW_GLU(f)                                                       \
+  {                                                                      \
+    const float gl = asw::gn_glu_value(buf[u].f, gate[u].f, gm0, gr0, gm1, gr1, gga.f, gba.f, ggg.f, gbg.f); \
+    o.f = okr[u] ? gl : 0.f;                                             \
+  }
+          ASW_GLU(x) ASW_GLU(y) ASW_GLU(z) ASW_GLU(w)
+#undef ASW_GLU
+          buf[u] = o;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1190,7 +1225,7 @@ void resconv16_kernel(const asw_convgemm_args p) {
 #endif
 }
 
-template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1)>
+template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1), bool GLU = false>
 int launch_res(const asw_convgemm_args& a, hipStream_t s) {
   constexpr int BMJ = BM / PH;
   const int RJ = BMJ + (!POLY ? (a.taps - 1) * a.dil : a.taps - 1);
@@ -1198,14 +1233,14 @@ int launch_res(const asw_convgemm_args& a, hipStream_t s) {
   const size_t slab = (size_t)(WM * 32) * (C + 4) * sizeof(float);
   const size_t smem = img > slab ? img : slab;
   if (smem > 160 * 1024) return 1;                     // caller falls back to the generic kernel
-  auto kern = resconv16_kernel<BM, C, WM, WN, PH, QD, POLY>;
+  auto kern = resconv16_kernel<BM, C, WM, WN, PH, QD, POLY, GLU>;
   static asw::SmemAttr attr;                            // per device
   if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
   const int gx = !POLY ? asw::cdiv(a.M_out, BM)
                        : asw::cdiv(asw::cdiv(a.M_out, a.dil), BMJ) * asw::cdiv(a.dil, PH);
   dim3 grid(gx, 1, a.B);
   char nm[96];
-  int nl = snprintf(nm, sizeof nm, "resconv16<%d,%d,%s%d%s>", BM, C, POLY ? "poly" : "ph", PH, QD == 2 ? ",q2" : "");
+  int nl = snprintf(nm, sizeof nm, "resconv16<%d,%d,%s%d%s%s>", BM, C, POLY ? "poly" : "ph", PH, QD == 2 ? ",q2" : "", GLU ? ",glu" : "");
   if (asw::prof_detail()) snprintf(nm + nl, sizeof nm - nl, "[B%d M%d N%d K%d d%d]", a.B, a.M_out, a.N, a.taps * a.Cin, a.dil);
   asw::ProfScope prof(s, nm, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, a);
@@ -1257,6 +1292,11 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
     case 64:
       // at C = 64 even dilation 7 is better off as 7 single-phase tiles (halo 6 instead of 42 rows per
       // 128 outputs, image 36 instead of 46 KB -> 4 resident workgroups): 238 -> 257 TFLOP/s
+      if (a.glu_raw) {
+        ASW_CHECK_ARG(a.dil == 1 && a.glu_mr && a.glu_gamma && a.glu_beta,
+                      "convgemm: GroupNorm + GLU on load needs dilation 1 and the statistics / affine arrays");
+        return launch_res<128, 64, 2, 2, 1, 4, false, true>(a, s);
+      }
       if (a.dil >= 7 && a.dil < 16 && rows_per_phase >= 96) return launch_res<128, 64, 2, 2, 1, 4, true>(a, s);
       if (!poly) return launch_res<128, 64, 2, 2, 1>(a, s);
       if (rows_per_phase >= 96) return launch_res<128, 64, 2, 2, 1, 4, true>(a, s);
@@ -1452,6 +1492,8 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
       const int rc = try_resconv(a, s);
       if (rc != 1) return rc;
     }
+    ASW_CHECK_ARG(!a.glu_raw, "convgemm: GroupNorm + GLU on load exists only in the halo-staged f16x3 layer "
+                              "(C_in == N == 64, dilation 1, fragment-order weights)");
     switch (a.N) {
       case 64: return launch_prec<256, 64, 32, 4, 1, true, false>(a, s);
       case 128: return launch_prec<128, 128, 32, 2, 2, true, false>(a, s);
@@ -1462,6 +1504,7 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
         return asw::set_error(ASW_ERR_ARG, "convgemm: LayerNorm width %d unsupported (64..1024, power of 2)", a.N);
     }
   }
+  ASW_CHECK_ARG(!a.glu_raw, "convgemm: GroupNorm + GLU on load belongs to a residual layer (LayerNorm + residual)");
   if (wide_tile(a.N)) {
     if (a.precision == 1) {
       // f16x3 is bound by the bytes each CU can pull per cycle, so take the largest tile the

@@ -26,13 +26,9 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // Statistics arrive as per-tile partial sums from the producing GEMM's epilogue and are
 // reduced here in double (deterministic, no atomics).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_glu_kernel(const float* __restrict__ raw, const float* __restrict__ stats,
-                                                     int n_partials, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, int T, int C, float eps,
-                                                     float* __restrict__ out, int items_per_block) {
-  __shared__ double red[4][4];
-  __shared__ float mr[4];                 // mean0, rstd0, mean1, rstd1
-  const int b = blockIdx.y;
+// (mean0, rstd0, mean1, rstd1) of batch item b from the partial sums, by a 256-thread workgroup; ends on a barrier
+__device__ __forceinline__ void gn_group_stats(const float* __restrict__ stats, int n_partials, int b, int T, int C, float eps,
+                                               double (&red)[4][4], float (&mr)[4]) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   double s[4] = {0, 0, 0, 0};
   const float* sp = stats + (long)b * n_partials * 4;
@@ -58,6 +54,25 @@ __global__ __launch_bounds__(256) void gn_glu_kernel(const float* __restrict__ r
     mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
+}
+
+// the statistics alone, for a consumer that normalises while it loads (asw_convgemm_args.glu_raw)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ stats, int n_partials, int T, int C,
+                                                          float eps, float* __restrict__ out) {
+  __shared__ double red[4][4];
+  __shared__ float mr[4];
+  gn_group_stats(stats, n_partials, blockIdx.x, T, C, eps, red, mr);
+  if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = mr[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void gn_glu_kernel(const float* __restrict__ raw, const float* __restrict__ stats,
+                                                     int n_partials, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int T, int C, float eps,
+                                                     float* __restrict__ out, int items_per_block) {
+  __shared__ double red[4][4];
+  __shared__ float mr[4];                 // mean0, rstd0, mean1, rstd1
+  const int b = blockIdx.y;
+  gn_group_stats(stats, n_partials, b, T, C, eps, red, mr);
   const float m0 = mr[0], r0 = mr[1], m1 = mr[2], r1 = mr[3];
   const int c4n = C >> 2;
   const long total = (long)T * c4n;
@@ -75,9 +90,7 @@ __global__ __launch_bounds__(256) void gn_glu_kernel(const float* __restrict__ r
     float4 o;
 #define ASW_GLU(f)                                              \
   {                                                             \
-    const float av = (a.f - m0) * r0 * ga.f + ba.f;             \
-    const float gv = (g.f - m1) * r1 * gg.f + bg.f;             \
-    o.f = av / (1.0f + expf(-gv));                              \
+    o.f = asw::gn_glu_value(a.f, g.f, m0, r0, m1, r1, ga.f, ba.f, gg.f, bg.f); \
   }
     ASW_GLU(x) ASW_GLU(y) ASW_GLU(z) ASW_GLU(w)
 #undef ASW_GLU
@@ -481,6 +494,14 @@ extern "C" int asw_gn_glu(const float* raw, const float* stats, int n_partials, 
   dim3 grid(asw::cdiv((long)T * (C / 4), items), B);
   hipLaunchKernelGGL(gn_glu_kernel, grid, dim3(256), 0, asw::as_stream(stream), raw, stats, n_partials, gamma, beta,
                      T, C, eps, out, items);
+  ASW_LAUNCH_CHECK();
+  return ASW_OK;
+}
+
+extern "C" int asw_gn_finalize(const float* stats, int n_partials, int B, int T, int C, float eps, float* mr, void* stream) {
+  ASW_CHECK_ARG(stats && mr, "gn_finalize: null pointer");
+  ASW_CHECK_ARG(B > 0 && T > 0 && C > 0 && n_partials > 0, "gn_finalize: bad shape");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, asw::as_stream(stream), stats, n_partials, T, C, eps, mr);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }

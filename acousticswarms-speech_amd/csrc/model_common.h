@@ -146,14 +146,24 @@ struct Arena {
 };
 
 
+// Input of a residual stack given as the un-normalised output of the preceding (transposed) convolution:
+// the first layer applies GroupNorm + GLU while it stages its rows (asw_convgemm_args.glu_raw).
+struct GluSrc { const float* raw; const float* mr; const float* gamma; const float* beta; };
+
+// f16x3, 64 channels, first layer of dilation 1 with fragment-order weights: the layer that can do it
+inline bool glu_on_load_ok(const std::vector<ResLayer>& res, int prec, int ch) {
+  return prec == 1 && ch == 64 && !res.empty() && res[0].dil == 1 && res[0].wt.fhi && res[0].wt.flo;
+}
+
 inline int run_res(const std::vector<ResLayer>& res, int prec, int B, int T, int ch, int K, float* x, float* p, float* q,
-            float** final_out, hipStream_t s) {
+            float** final_out, hipStream_t s, const GluSrc* glu = nullptr) {
   // ping-pong: layer 0 reads x (kept intact), later layers alternate p/q
-  const float* in = x;
+  const float* in = glu ? glu->raw : x;
   float* outb = p;
   for (size_t j = 0; j < res.size(); ++j) {
     asw_convgemm_args a = {};
     a.A = in; res[j].wt.bind(a, prec); a.bias = res[j].bias.p; a.resid = in;
+    if (glu && j == 0) { a.glu_raw = glu->raw; a.glu_mr = glu->mr; a.glu_gamma = glu->gamma; a.glu_beta = glu->beta; }
     a.ln_gamma = res[j].g.p; a.ln_beta = res[j].b.p; a.out = outb;
     a.B = B; a.M_out = T; a.N = ch; a.Cin = ch; a.taps = K; a.stride = 1; a.dil = res[j].dil;
     a.pad = (res[j].dil * (K - 1) + 1) / 2;

@@ -186,7 +186,7 @@ struct Plan {
   std::vector<int> Tl;
   float *mean, *stdv, *refn;
   double* jscr;
-  std::vector<float*> X, Pb, Qb, raw_dn, raw_up, st_dn, st_up;
+  std::vector<float*> X, Pb, Qb, raw_dn, raw_up, st_dn, st_up, mr_up;
   std::vector<float*> intra_out, inter_out;   // per bottleneck layer (kept apart so every tap stays readable)
   float *h, *g, *x1, *x2, *x3, *qkv, *ctx, *raw2, *u, *v2, *y, *f, *pos;
   float *Y, *D, *ywave;
@@ -215,6 +215,7 @@ void layout(const asw_sep* m, int NB, int S, int T, Arena& a, Plan& pl) {
   pl.refn = a.take<float>((size_t)BS * pl.RL);
   pl.X.resize(c.depth + 1); pl.Pb.resize(c.depth); pl.Qb.resize(c.depth);
   pl.raw_dn.resize(c.depth); pl.raw_up.resize(c.depth); pl.st_dn.resize(c.depth); pl.st_up.resize(c.depth);
+  pl.mr_up.resize(c.depth);
   for (int i = 0; i <= c.depth; ++i) {
     const int ch = i == 0 ? c.channels : m->enc_cout[i - 1];
     pl.X[i] = a.take<float>((size_t)BS * pl.Tl[i] * ch);
@@ -231,6 +232,7 @@ void layout(const asw_sep* m, int NB, int S, int T, Arena& a, Plan& pl) {
     const int s = m->dec_stride[j], co2 = 2 * m->dec_cout[j];
     pl.raw_up[j] = a.take<float>((size_t)BS * pl.Tl[lvl] * s * co2);
     pl.st_up[j] = a.take<float>((size_t)BS * 4 * asw_convgemm_stats_tiles(pl.Tl[lvl], s * co2));
+    pl.mr_up[j] = a.take<float>((size_t)BS * 4);
   }
   const size_t L = pl.Tl[c.depth], d = m->enc_cout.back(), rows = (size_t)BS * L;
   pl.L = (int)L; pl.d = (int)d;
@@ -377,11 +379,20 @@ int run_network(asw_sep* m, Plan& pl, const float* mean, const float* stdv, floa
     if ((rc = asw_convgemm_f32(&a, s))) return rc;
     const int To = pl.Tl[lvl] * st;
     float* g = pl.Qb[lvl - 1];
-    if ((rc = asw_gn_glu(pl.raw_up[j], pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), m->dec[j].gn_g.p,
-                         m->dec[j].gn_b.p, B, To, co, 1e-5f, g, s)))
-      return rc;
     float* r = nullptr;
-    if ((rc = run_res(m->dec[j].res, m->precision, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s))) return rc;
+    if (true && glu_on_load_ok(m->dec[j].res, m->precision, co)) {
+      // 64-channel blocks: GroupNorm + GLU happen while the first residual layer stages its rows -- the
+      // normalised tensor is neither written nor read back (P -> g -> P are the stack's own buffers)
+      if ((rc = asw_gn_finalize(pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), B, To, co, 1e-5f, pl.mr_up[j], s))) return rc;
+      const GluSrc src = {pl.raw_up[j], pl.mr_up[j], m->dec[j].gn_g.p, m->dec[j].gn_b.p};
+      if ((rc = run_res(m->dec[j].res, m->precision, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s, &src))) return rc;
+    } else {
+      if ((rc = asw_gn_glu(pl.raw_up[j], pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), m->dec[j].gn_g.p,
+                           m->dec[j].gn_b.p, B, To, co, 1e-5f, g, s)))
+        return rc;
+      // residual ping-pong: g -> P -> g -> P ...
+      if ((rc = run_res(m->dec[j].res, m->precision, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s))) return rc;
+    }
     x = r;
     m->taps["dec" + std::to_string(j)] = {x, (size_t)B * To * co};
   }

@@ -220,7 +220,7 @@ struct Plan {
   std::vector<int> Tl;                     // length at level 0..depth
   float *mean, *stdv, *refn;
   std::vector<float*> X, Pb, Qb;           // level tensors: X[i] input of enc block i (X[0]=preproc out)
-  std::vector<float*> raw_dn, raw_up, st_dn, st_up;
+  std::vector<float*> raw_dn, raw_up, st_dn, st_up, mr_up;
   float *qkv, *ctx, *x1, *ff, *ha, *hb, *Y, *D, *ywave;
   double *escr;
 };
@@ -239,6 +239,7 @@ void layout(const asw_spot* m, int B, int T, Arena& a, Plan& pl) {
   pl.refn = a.take<float>((size_t)B * pl.RL);
   pl.X.resize(c.depth + 1); pl.Pb.resize(c.depth); pl.Qb.resize(c.depth);
   pl.raw_dn.resize(c.depth); pl.raw_up.resize(c.depth); pl.st_dn.resize(c.depth); pl.st_up.resize(c.depth);
+  pl.mr_up.resize(c.depth);
   for (int i = 0; i <= c.depth; ++i) {
     const int ch = i == 0 ? c.channels : m->enc_cout[i - 1];
     pl.X[i] = a.take<float>((size_t)B * pl.Tl[i] * ch);
@@ -255,6 +256,7 @@ void layout(const asw_spot* m, int B, int T, Arena& a, Plan& pl) {
     const int s = m->dec_stride[j], co2 = 2 * m->dec_cout[j];
     pl.raw_up[j] = a.take<float>((size_t)B * pl.Tl[lvl] * s * co2);
     pl.st_up[j] = a.take<float>((size_t)B * 4 * asw_convgemm_stats_tiles(pl.Tl[lvl], s * co2));
+    pl.mr_up[j] = a.take<float>((size_t)B * 4);
   }
   const size_t L = pl.Tl[c.depth], d = m->enc_cout.back();
   pl.qkv = a.take<float>((size_t)B * L * 3 * d);
@@ -337,12 +339,20 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
     if ((rc = asw_convgemm_f32(&a, s))) return rc;
     const int To = pl.Tl[lvl] * st;          // == pl.Tl[lvl-1]
     float* g = pl.Qb[lvl - 1];
-    if ((rc = asw_gn_glu(pl.raw_up[j], pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), m->dec[j].gn_g.p,
-                         m->dec[j].gn_b.p, B, To, co, 1e-5f, g, s)))
-      return rc;
     float* r = nullptr;
-    // residual ping-pong: g -> P -> g -> P ...
-    if ((rc = run_res(m->dec[j].res, m->precision, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s))) return rc;
+    if (m->fuse_mask && glu_on_load_ok(m->dec[j].res, m->precision, co)) {
+      // 64-channel blocks: GroupNorm + GLU happen while the first residual layer stages its rows -- the
+      // normalised tensor is neither written nor read back (P -> g -> P are the stack's own buffers)
+      if ((rc = asw_gn_finalize(pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), B, To, co, 1e-5f, pl.mr_up[j], s))) return rc;
+      const GluSrc src = {pl.raw_up[j], pl.mr_up[j], m->dec[j].gn_g.p, m->dec[j].gn_b.p};
+      if ((rc = run_res(m->dec[j].res, m->precision, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s, &src))) return rc;
+    } else {
+      if ((rc = asw_gn_glu(pl.raw_up[j], pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), m->dec[j].gn_g.p,
+                           m->dec[j].gn_b.p, B, To, co, 1e-5f, g, s)))
+        return rc;
+      // residual ping-pong: g -> P -> g -> P ...
+      if ((rc = run_res(m->dec[j].res, m->precision, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s))) return rc;
+    }
     x = r;
     m->taps["dec" + std::to_string(j)] = {x, (size_t)B * To * co};
   }

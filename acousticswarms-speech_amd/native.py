@@ -121,7 +121,8 @@ class ConvGemmArgs(Structure):
                 ("stride", c_int32), ("dil", c_int32), ("pad", c_int32), ("a_row_stride", c_int32),
                 ("a_batch_stride", c_int64), ("a_len", c_int64), ("chan_mod", c_int32), ("relu", c_int32),
                 ("ln_eps", c_float), ("precision", c_int32), ("w_shift", c_int32), ("Wt_hi", c_void_p),
-                ("Wt_lo", c_void_p), ("Wf_hi", c_void_p), ("Wf_lo", c_void_p), ("stats_stride", c_int32)]
+                ("Wt_lo", c_void_p), ("Wf_hi", c_void_p), ("Wf_lo", c_void_p), ("stats_stride", c_int32),
+                ("glu_raw", c_void_p), ("glu_mr", c_void_p), ("glu_gamma", c_void_p), ("glu_beta", c_void_p)]
 
 
 class MaskPathArgs(Structure):
@@ -180,6 +181,7 @@ SIGNATURES = {
     "asw_f16x3_overflow_count": (c_int, [c_int, POINTER(c_int32)]),
     "asw_gn_glu": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                            c_void_p]),
+    "asw_gn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "asw_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "asw_overlap_add_unnorm": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),

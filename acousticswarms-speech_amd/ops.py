@@ -24,7 +24,7 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, relu=False, resid=None, mul=None,
              ln=None, stats_chan_mod=0, A2=None, B=None, a_row_stride=None, a_batch_stride=None, a_len=None,
-             out=None, ln_eps=1e-5, precision="f32", use_fragments=True):
+             out=None, ln_eps=1e-5, precision="f32", use_fragments=True, glu=None):
     """out[b][r][n] per include/asw_hip.h:asw_convgemm_f32.  Returns (out, stats|None)."""
     _f32(A); _f32(Wt)
     if B is None:
@@ -52,6 +52,8 @@ def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, re
     a.B, a.M_out, a.N, a.Cin, a.taps, a.stride, a.dil, a.pad = B, M_out, N, Cin, taps, stride, dil, pad
     a.a_row_stride, a.a_batch_stride, a.a_len = a_row_stride, a_batch_stride, a_len
     a.chan_mod, a.relu, a.ln_eps = stats_chan_mod, int(relu), ln_eps
+    if glu is not None:                      # (raw [B][M_out][2N], mr [B][4], gamma [2N], beta [2N]): GroupNorm + GLU on load
+        a.glu_raw, a.glu_mr, a.glu_gamma, a.glu_beta = (_f32(t).data_ptr() for t in glu)
     keep = None
     if precision == "f16x3":
         hi, lo, shift = split_weights_f16(Wt)
@@ -103,6 +105,14 @@ def gn_glu(raw, stats, gamma, beta, eps=1e-5):
     check(lib().asw_gn_glu(ptr(_f32(raw)), ptr(_f32(stats)), stats.shape[1], ptr(_f32(gamma)), ptr(_f32(beta)),
                            B, T, C, eps, ptr(out), current_stream()))
     return out
+
+
+def gn_finalize(stats, T, C, eps=1e-5):
+    """Partial GroupNorm sums [B][n][4] -> (mean0, rstd0, mean1, rstd1) per batch item (asw_gn_finalize)."""
+    B = stats.shape[0]
+    mr = torch.empty((B, 4), dtype=torch.float32, device=stats.device)
+    check(lib().asw_gn_finalize(ptr(_f32(stats)), stats.shape[1], B, T, C, eps, ptr(mr), current_stream()))
+    return mr
 
 
 def add_layernorm(x, resid, gamma, beta, eps=1e-5):

@@ -116,8 +116,10 @@ int asw_spot_forward(asw_spot* m, const float* mix_norm, int B, int M, int t,
 
 /* f16x3 mode runs the mask path (reference_bypass, mask_encoder, product, output_decoder taps) as ONE
  * launch (asw_mask_path_f16x3) when the shapes fit (encoder_channels % 256 == 0, channels % 32 == 0,
- * kernel <= 48): the latent is then never written and the "latent" tap does not exist.  on = 0
- * selects the three-GEMM path (default: on). */
+ * kernel <= 48): the latent is then never written and the "latent" tap does not exist; and the
+ * 64-channel decoder blocks apply GroupNorm + GLU while their first residual layer loads its rows
+ * (asw_convgemm_args.glu_raw).  on = 0 selects the three-GEMM mask path and the separate GroupNorm + GLU
+ * pass everywhere (default: on). */
 int asw_spot_set_fused_mask(asw_spot* m, int on);
 
 /* Debug/parity tap: copy an intermediate activation of the LAST forward to `dst`
@@ -282,6 +284,16 @@ typedef struct asw_convgemm_args {
   const void* Wf_hi;
   const void* Wf_lo;
   int32_t stats_stride;   /* set by the library: partial-statistics slots per batch item */
+  /* Optional (precision 1, the halo-staged residual layer with C_in == N == 64, dilation 1, i.e. the first
+   * layer of the decoder blocks' residual stacks): take the layer's input -- and residual -- from the
+   * un-normalised output of the preceding transposed convolution instead of A, applying GroupNorm(2) + GLU
+   * while the rows are staged (the arithmetic of asw_gn_glu, bit for bit), so that tensor is neither written
+   * nor read back.  glu_raw [B][M_out][128] (value half | gate half of every output row), glu_mr [B][4] =
+   * (mean0, rstd0, mean1, rstd1) from asw_gn_finalize, glu_gamma / glu_beta [128].  A is ignored. */
+  const float* glu_raw;
+  const float* glu_mr;
+  const float* glu_gamma;
+  const float* glu_beta;
 } asw_convgemm_args;
 /* Host helper: fp32 Wt[N][K] -> fragment-major fp16 hi/lo [K/16][N/32][64 lanes][8]:
  * lane l of fragment (ks, nt) holds Wt[nt*32 + (l&31)][ks*16 + 8*(l>>5) + j], j < 8, i.e.
@@ -341,6 +353,10 @@ int asw_convgemm_stats_tiles(int M_out, int N);
  * statistics written by asw_convgemm_f32 (network.py:107-113,194-197). */
 int asw_gn_glu(const float* raw, const float* stats, int n_partials, const float* gamma,
                const float* beta, int B, int T, int C, float eps, float* out, void* stream);
+/* The statistics half of asw_gn_glu alone: reduces the same partial sums the same way and writes
+ * mr [B][4] = (mean0, rstd0, mean1, rstd1) (float32), for a consumer that normalises while it loads
+ * (asw_convgemm_args.glu_raw). */
+int asw_gn_finalize(const float* stats, int n_partials, int B, int T, int C, float eps, float* mr, void* stream);
 
 /* Multi-head self-attention core: qkv [B][L][3*d] (in_proj output) -> ctx [B][L][d]
  * (softmax(QK^T/sqrt(hd))V per head); nn.MultiheadAttention inside

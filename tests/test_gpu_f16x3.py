@@ -120,6 +120,33 @@ def test_shift_and_sep_full_f16x3_vs_reference_golden(golden):
     assert min(snr_db(y32[i], g["y_strict1"][i]) for i in range(5)) > 100.0
 
 
+@pytest.mark.parametrize("T", [1000, 128, 77])
+def test_groupnorm_glu_on_load_is_bit_identical(T):
+    """The first residual layer of a 64-channel decoder block can take its input as the un-normalised
+    2 x 64-channel tensor and apply GroupNorm(2) + GLU while it stages its rows (asw_convgemm_args.glu_raw):
+    same bits as asw_gn_glu followed by the plain layer, including the zero padding at both ends."""
+    from acousticswarms_speech_amd import ops
+    B, C, K = 3, 64, 7
+    raw = (_rand(B, T, 2 * C, seed=70) * 1.7 + 0.3).cuda()
+    gamma, beta = (1 + 0.2 * _rand(2 * C, seed=71)).cuda(), (0.1 * _rand(2 * C, seed=72)).cuda()
+    w = _rand(C, C, K, seed=73, scale=1 / math.sqrt(C * K))
+    bias, lg, lb = _rand(C, seed=74, scale=0.1).cuda(), (1 + 0.1 * _rand(C, seed=75)).cuda(), (0.1 * _rand(C, seed=76)).cuda()
+    r = raw.double()
+    stats = torch.stack([r[..., :C].sum((1, 2)), (r[..., :C] ** 2).sum((1, 2)), r[..., C:].sum((1, 2)),
+                         (r[..., C:] ** 2).sum((1, 2))], dim=1).float().view(B, 1, 4).contiguous()
+    g = ops.gn_glu(raw, stats, gamma, beta)
+    Wt = ops.pack_conv_weight(w).cuda()
+    kw = dict(taps=K, pad=3, bias=bias, relu=True, ln=(lg, lb), precision="f16x3")
+    want, _ = ops.convgemm(g, Wt, T, C, C, resid=g, **kw)
+    mr = ops.gn_finalize(stats, T, C)
+    got, _ = ops.convgemm(raw, Wt, T, C, C, resid=raw, a_batch_stride=T * C, a_len=T * C, B=B,
+                          glu=(raw, mr, gamma, beta), **kw)
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError):                # any other layer shape refuses instead of ignoring the request
+        ops.convgemm(raw, Wt, T, C, C, resid=raw, a_batch_stride=T * C, a_len=T * C, B=B, dil=7, glu=(raw, mr, gamma, beta),
+                     **dict(kw, pad=21))
+
+
 def test_fused_mask_path_matches_three_gemm_path(golden):
     """f16x3 runs the mask path as one launch by default (asw_mask_path_f16x3: no latent in memory); the
     three-GEMM path stays selectable.  Both against the reference's own output (g4b) and against each
