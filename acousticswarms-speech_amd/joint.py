@@ -18,10 +18,21 @@ from .mic_array import MicArray
 
 
 def _sync():
+    """Stage boundary: every stream of the device drained, then one event round trip on the current stream.
+    The round trip is not decoration.  After hipDeviceSynchronize / hipStreamSynchronize alone the ROCm 7.2
+    runtime intermittently (about every second forward) starts the FIRST command of the next stage 20-25 ms
+    late: the whole stage is enqueued within a few ms but nothing executes until that long into the stage's
+    final blocking copy (rocprofv3 --hip-trace --kernel-trace; the separation stage read 23 or 45-60 ms,
+    tests/micro/e2e_stats.py).  With a hipEventRecord + hipEventSynchronize after the drain the next
+    submission is dispatched at once: 12 of 12 forwards at 23 ms.  (Event record without the wait, stream
+    synchronize, or no synchronisation at all: the late start stays.)"""
     try:
         import torch
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
     except ImportError:          # pragma: no cover
         pass
 
