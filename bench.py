@@ -256,6 +256,11 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        # + one event round trip: after a bare device synchronize the runtime intermittently starts the next
+        # submission 20-25 ms late; the stage boundaries of the pipeline do the same
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
 
     def timed(step, steps, warmup):
         for _ in range(warmup):
