@@ -169,6 +169,49 @@ extern "C" void asw_free(void* p) { std::free(p); }
 // hyperbola_area_sample (sep/Traditional_SP/SRP_Prunning.py:19-61) over a sub-box
 // [y0,y1) x [x0,x1) x all z of a lookup table offsets[ny][nx][nz][P].  Writes the flat indices
 // ((y*nx + x)*nz + z) of the hits in scan order (the order of the reference's boolean mask).
+// The same scan over a table stored pair-major, planes[P][ny][nx][nz]: almost every point fails on the first
+// pair, so the scan streams 8 bytes per point instead of the 8 P of the interleaved layout (the 30 cubes of one
+// SRP-PHAT stage visit 3.2 M points: 25 -> 4 ms on the build host).  Same comparisons, same order.
+extern "C" int asw_cube_select_planes(const double* planes, int ny, int nx, int nz, int P, int y0, int y1, int x0, int x1,
+                                      const double* lo, const double* hi, int32_t* out_idx, int64_t cap, int64_t* count) {
+  ASW_CHECK_ARG(planes && lo && hi && out_idx && count, "cube_select: null pointer");
+  ASW_CHECK_ARG(ny > 0 && nx > 0 && nz > 0 && P > 0 && 0 <= y0 && y0 <= y1 && y1 <= ny && 0 <= x0 && x0 <= x1 && x1 <= nx,
+                "cube_select: bad box");
+  const size_t plane = (size_t)ny * nx * nz;
+  const double l0 = lo[0], h0 = hi[0];
+  int64_t n = 0;
+  for (int y = y0; y < y1; ++y) {
+    const size_t i0 = ((size_t)y * nx + x0) * nz, i1 = ((size_t)y * nx + x1) * nz;   // one contiguous run per row
+    size_t i = i0;
+    while (i < i1) {
+      // first pair, eight points at a time without a branch (the compiler vectorises the block); the rare
+      // survivors are then checked against the other pairs in scan order
+      const size_t blk = i1 - i < 8 ? i1 - i : 8;
+      unsigned m = 0;
+      if (blk == 8) {
+        for (int k = 0; k < 8; ++k) m |= (unsigned)((planes[i + k] >= l0) & (planes[i + k] <= h0)) << k;
+      } else {
+        for (size_t k = 0; k < blk; ++k) m |= (unsigned)((planes[i + k] >= l0) & (planes[i + k] <= h0)) << k;
+      }
+      for (size_t k = 0; m; ++k, m >>= 1) {
+        if (!(m & 1u)) continue;
+        bool in = true;
+        for (int p = 1; p < P; ++p) {
+          const double v = planes[(size_t)p * plane + i + k];
+          if (!(v >= lo[p] && v <= hi[p])) { in = false; break; }
+        }
+        if (in) {
+          if (n >= cap) return asw::set_error(ASW_ERR_ARG, "cube_select: output capacity %lld too small", (long long)cap);
+          out_idx[n++] = (int32_t)(i + k);
+        }
+      }
+      i += blk;
+    }
+  }
+  *count = n;
+  return ASW_OK;
+}
+
 extern "C" int asw_cube_select(const double* offsets, int ny, int nx, int nz, int P, int y0, int y1, int x0, int x1,
                                const double* lo, const double* hi, int32_t* out_idx, int64_t cap, int64_t* count) {
   ASW_CHECK_ARG(offsets && lo && hi && out_idx && count, "cube_select: null pointer");

@@ -198,6 +198,8 @@ SIGNATURES = {
     "asw_free": (None, [c_void_p]),
     "asw_cube_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p, c_int64, POINTER(c_int64)]),
+    "asw_cube_select_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                c_void_p, c_int64, POINTER(c_int64)]),
     "asw_srp_frames": (c_int, [c_int, c_int, c_int]),
     "asw_srp_cross_spectra": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -82,6 +82,9 @@ class SRPPhat(object):
         # 5 cm and 1 cm lookup grids with their TDoA vectors (:149-170)
         self.Pos_5, self.Offset_5 = self._lookup_grid(0.05)
         self.Pos_1, self.Offset_1 = self._lookup_grid(0.01)
+        # pair-major copies for the cube scans (asw_cube_select_planes streams one pair's plane)
+        self._planes_5 = np.ascontiguousarray(np.moveaxis(self.Offset_5, 3, 0))
+        self._planes_1 = np.ascontiguousarray(np.moveaxis(self.Offset_1, 3, 0))
 
         keepout = 0.2                                       # :174-180
         self.array_border = [self.mic_pos[:, 0].min() - keepout, self.mic_pos[:, 1].min() - keepout,
@@ -269,7 +272,7 @@ class SRPPhat(object):
     def hyperbola_area_init(self, sample_offsets, width):
         """3-D points (1 cm grid) whose TDoA lies inside the cube, found through the 5 cm
         grid's bounding box (:41-61).  Returns [3,n] or None."""
-        pts = self._cube_points(self.Pos_5, self.Offset_5, sample_offsets, width)
+        pts = self._cube_points(self.Pos_5, self._planes_5, sample_offsets, width)
         if pts.shape[0] == 0:
             return None
         ax = self.Axis_range
@@ -277,16 +280,17 @@ class SRPPhat(object):
         y0, y1 = max(ax[1][0], pts[:, 1].min() - 0.05), min(ax[1][1], pts[:, 1].max() + 0.05)
         xi0, xi1 = int(np.floor((x0 - ax[0][0]) / 0.01)), int(np.ceil((x1 - ax[0][0]) / 0.01))
         yi0, yi1 = int(np.floor((y0 - ax[1][0]) / 0.01)), int(np.ceil((y1 - ax[1][0]) / 0.01))
-        return self._cube_points(self.Pos_1, self.Offset_1, sample_offsets, width, yi0, yi1, xi0, xi1).T
+        return self._cube_points(self.Pos_1, self._planes_1, sample_offsets, width, yi0, yi1, xi0, xi1).T
 
     @staticmethod
-    def _cube_points(pos, off, center, width, y0=0, y1=None, x0=0, x1=None):
+    def _cube_points(pos, planes, center, width, y0=0, y1=None, x0=0, x1=None):
         """Points [n,3] of the lookup grid (sub-box [y0,y1) x [x0,x1)) whose TDoA lies within
         +-width/2 of ``center`` on every pair: the native box scan (csrc/search_host.cpp,
-        same comparisons and order as the boolean mask of ``_offsets_within``)."""
+        same comparisons and order as the boolean mask of ``_offsets_within``) over the
+        pair-major table ``planes`` [P, ny, nx, nz]."""
         from ctypes import byref, c_int64, c_void_p
         from . import native
-        ny, nx, nz, P = off.shape
+        P, ny, nx, nz = planes.shape
         y1 = ny if y1 is None else min(y1, ny)
         x1 = nx if x1 is None else min(x1, nx)
         y0, x0 = max(y0, 0), max(x0, 0)
@@ -297,7 +301,7 @@ class SRPPhat(object):
         cap = (y1 - y0) * (x1 - x0) * nz
         idx = np.empty(cap, dtype=np.int32)
         n = c_int64()
-        native.check(native.lib().asw_cube_select(c_void_p(off.ctypes.data), ny, nx, nz, P, y0, y1, x0, x1,
+        native.check(native.lib().asw_cube_select_planes(c_void_p(planes.ctypes.data), ny, nx, nz, P, y0, y1, x0, x1,
                                                   c_void_p(lo.ctypes.data), c_void_p(hi.ctypes.data),
                                                   c_void_p(idx.ctypes.data), cap, byref(n)))
         return pos.reshape(-1, 3)[idx[:n.value]]

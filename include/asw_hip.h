@@ -424,6 +424,10 @@ void asw_free(void* p);
  * (sep/Traditional_SP/SRP_Prunning.py:19-61). */
 int asw_cube_select(const double* offsets, int ny, int nx, int nz, int P, int y0, int y1, int x0, int x1,
                     const double* lo, const double* hi, int32_t* out_idx, int64_t cap, int64_t* count);
+/* The same scan over a pair-major table planes[P][ny][nx][nz] (8 bytes streamed per point instead of 8 P: the
+ * first pair rejects almost every point); identical comparisons, order and result. */
+int asw_cube_select_planes(const double* planes, int ny, int nx, int nz, int P, int y0, int y1, int x0, int x1,
+                    const double* lo, const double* hi, int32_t* out_idx, int64_t cap, int64_t* count);
 
 /* SRP-PHAT pruning map (sep/Traditional_SP/SRP_Prunning.py:387-434), two stages.
  *

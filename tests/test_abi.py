@@ -56,6 +56,19 @@ def test_host_entry_points_run_without_a_gpu():
     mask = np.zeros((5, 7, 3), dtype=bool)
     mask[1:4, 2:6] = np.all((off[1:4, 2:6] >= lo) & (off[1:4, 2:6] <= hi), axis=-1)
     np.testing.assert_array_equal(idx[:n.value], np.flatnonzero(mask))
+    # the pair-major variant: same hits, same order (ragged run lengths exercise the blocked first-pair test)
+    planes = np.ascontiguousarray(np.moveaxis(off, 3, 0))
+    idx2 = np.empty_like(idx)
+    for box in [(1, 4, 2, 6), (0, 5, 0, 7), (2, 3, 1, 2)]:
+        y0, y1, x0, x1 = box
+        native.check(L.asw_cube_select(c_void_p(off.ctypes.data), 5, 7, 3, 4, y0, y1, x0, x1, c_void_p(lo.ctypes.data),
+                                       c_void_p(hi.ctypes.data), c_void_p(idx.ctypes.data), idx.size, byref(n)))
+        n1 = n.value
+        native.check(L.asw_cube_select_planes(c_void_p(planes.ctypes.data), 5, 7, 3, 4, y0, y1, x0, x1,
+                                              c_void_p(lo.ctypes.data), c_void_p(hi.ctypes.data), c_void_p(idx2.ctypes.data),
+                                              idx2.size, byref(n)))
+        assert n.value == n1 and n1 > 0
+        np.testing.assert_array_equal(idx2[:n1], idx[:n1])
     # capacity too small -> status + message, no overrun
     assert L.asw_cube_select(c_void_p(off.ctypes.data), 5, 7, 3, 4, 0, 5, 0, 7, c_void_p((c - 100).ctypes.data),
                              c_void_p((c + 100).ctypes.data), c_void_p(idx.ctypes.data), 3, byref(n)) == -1
