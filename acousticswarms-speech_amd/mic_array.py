@@ -276,7 +276,14 @@ class MicArray(object):
                 g, big, patches, powers, powers2, areas[g], centers[g], T_len, thr_new, sample_gt,
                 lambda k, h, sep=sep: si_sdr(sep[k, :], sep[h]), lambda heads, sep=sep: [sep[h, :] for h in heads]))
         if sharded:
-            output_pair = spot_model.gather_pairs(output_pair)
+            # the voiced segments of every head travel with its tuple: the global clustering of every rank
+            # then finds them cached for the remote heads too, as it does for its own
+            tagged = [p + (self._seg_cache.get(id(p[1]), (None, None))[1],) for p in output_pair]
+            merged = spot_model.gather_pairs(tagged)
+            output_pair = [t[:-1] for t in merged]
+            for t, p in zip(merged, output_pair):
+                if t[-1] is not None:
+                    self._seg_cache[id(p[1])] = (p[1], t[-1])
         return output_pair
 
     def _fine_stage_pipelined(self, mix_data, candidate_finished, spot_model, sample_gt, thr_new):

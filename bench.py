@@ -197,7 +197,7 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if not args.stub and torch.cuda.device_count() < args.gpus:
+        if not args.stub and torch.cuda.device_count() < args.gpus and os.environ.get("ASW_BENCH_BACKEND", "nccl") == "nccl":
             raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} HIP devices visible")
         raise SystemExit(launch_ranks(args.gpus))
 
@@ -219,12 +219,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # ASW_BENCH_BACKEND=gloo is a REHEARSAL switch (tests / a one-GPU box): the ranks then share the visible
+    # devices and the collectives run on host tensors.  The measured multi-GPU path is RCCL ("nccl").
+    backend = os.environ.get("ASW_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")       # where the exchanged tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"{dist.get_world_size()} ranks joined, --gpus {args.gpus} asked")
 
@@ -244,9 +251,9 @@ def main():
         def step():
             _, en = mdl.shift_and_sep_device(mix_dev, my_off, strict=1, want_wave=False, want_energy=True, window=12000)
             if world > 1:
-                buf = torch.zeros((width, 2), dtype=torch.float64, device=dev)
-                buf[:en.shape[0]] = en
-                out = torch.empty((world * width, 2), dtype=torch.float64, device=dev)
+                buf = torch.zeros((width, 2), dtype=torch.float64, device=coll_dev)
+                buf[:en.shape[0]] = en.to(coll_dev)
+                out = torch.empty((world * width, 2), dtype=torch.float64, device=coll_dev)
                 dist.all_gather_into_tensor(out, buf)          # the stage's one exchange
                 return out
             return en
@@ -272,7 +279,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         assert torch.isfinite(last).all()
@@ -298,7 +305,7 @@ def main():
         L.asw_profile_enable(0)
         prof = json.loads(buf.value.decode())
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(last).all()
@@ -327,6 +334,7 @@ def main():
                                  "note": "3 s at the reference's native 48 kHz"}
             del mix3
 
+    line = None
     if rank == 0:
         fl = flops_per_candidate(cfg, T)
         value = n_total * args.steps / dt
@@ -366,7 +374,7 @@ def main():
                                        "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
         e2e = None
-        if not args.no_e2e:
+        if not args.no_e2e and world == 1:
             e2e = e2e_latency(model, build_sep_model(dev, args.precision), scene, dev)
         cpu = refstyle = None
         if world == 1:                                   # baselines: reported on rank 0 at N = 1 only
@@ -391,10 +399,42 @@ def main():
             "vs_refstyle_gpu": (round(value / refstyle["value"], 2) if refstyle else None),
             "extras": extras or None, "e2e_latency": e2e,
         }
+    # ---- end-to-end latency on N ranks: the same pipeline with the candidates of the coarse and the fine stage
+    # sharded over the ranks (shard.ShardedSpotModel: one energy all-gather per stage, one object gather of the
+    # cluster heads); SRP-PHAT, the global clustering and the separation call are replica work.  Every rank takes
+    # part.  The throughput line is complete before this starts: a watchdog turns a hung collective into a
+    # reported error (rank 0 still prints the line) instead of a hung or failed run.
+    if world > 1 and not args.no_e2e:
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("ASW_E2E_TIMEOUT_S", "240"))):
+                if rank == 0:
+                    line["e2e_latency"] = {"error": "multi-rank end-to-end measurement timed out"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            from acousticswarms_speech_amd.shard import ShardedSpotModel
+            e2e_sharded = e2e_latency(ShardedSpotModel(model, device=coll_dev), build_sep_model(dev, args.precision), scene, dev)
+            e2e_sharded["ranks"] = world
+            e2e_sharded["note"] = ("candidates of the coarse and the fine stage sharded over the ranks; SRP-PHAT, global "
+                                   "clustering and the separation call replicated")
+        except Exception as exc:                          # reported, not fatal: the throughput line stands
+            e2e_sharded = {"error": f"{type(exc).__name__}: {exc}"}
+        done.set()
+        if rank == 0:
+            line["e2e_latency"] = e2e_sharded
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        # the line is out; a rank that failed above must not turn the closing barrier into a ten-minute hang
+        import threading
+        threading.Timer(60.0, lambda: os._exit(0)).start()
         dist.barrier()
         dist.destroy_process_group()
+        os._exit(0)
 
 
 def build_sep_model(dev, precision):

@@ -254,3 +254,30 @@ def test_bench_two_ranks_over_rccl():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["config"]["parallelism"] == "candidate-shard x2"
+
+
+def test_bench_two_ranks_rehearsal_sharing_one_gpu():
+    """The multi-rank code path of bench.py end to end on a one-GPU box: two ranks started by bench.py
+    itself (torch.distributed.run), the collectives on the gloo backend over host tensors
+    (ASW_BENCH_BACKEND=gloo, a rehearsal switch: the measured path is RCCL), both ranks on the visible GPU.
+    Checks what the driver relies on at N > 1: one JSON line from rank 0, n_gpus, weak scaling, the energy
+    exchange of every step, and the end-to-end latency of the SHARDED pipeline (coarse and fine candidates
+    split over the ranks) with the same stage trace as one GPU."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["ASW_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-extras", "--cpu-sample", "0", "--candidates", "32", "--batch", "32"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    e2e = line["e2e_latency"]
+    assert "error" not in e2e, e2e
+    assert e2e["ranks"] == 2 and e2e["spot_calls"] == {"coarse": 30, "fine": 710} and e2e["talkers_found"] == 27
+    assert e2e["separated_rows"] == 27 and e2e["total"] > 0
