@@ -268,6 +268,41 @@ def test_mask_path_fused(ops, B, E, Tp, t):
     assert rel < 3e-6
 
 
+@pytest.mark.parametrize("n,T", [(5, 1003), (17, 4099), (70, 2500)])
+def test_tiled_sisdr_kernels_on_ragged_shapes(n, T):
+    """pair_sisdr / segment_sisdr (tiled Gram kernels: 16 x 16 pairs, one estimate x 64 references, 64-sample
+    chunks) where neither n nor T nor the segment bounds fill a tile, against the host si_sdr of the same rows
+    (float32 numpy arithmetic: 1e-3 dB); a row compared with itself hits the residual clamp."""
+    from acousticswarms_speech_amd.config import SMALL
+    from acousticswarms_speech_amd.hostdsp import si_sdr
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    rng = np.random.default_rng(100 + n)
+    base = rng.standard_normal((3, T)).astype(np.float32)
+    a = (rng.standard_normal((n, 3)).astype(np.float32) @ base + 0.2 * rng.standard_normal((n, T)).astype(np.float32))
+    m = SpotModel(SMALL, make_spot_state_dict(SMALL, 1), batch_size=4).to("cuda")
+    waves = torch.from_numpy(a).cuda()
+    S = m.pair_sisdr(waves)
+    segs = []
+    for i in range(n):
+        k = int(rng.integers(0, 4))
+        cuts = np.sort(rng.choice(np.arange(1, T), size=2 * k, replace=False)) if k else np.zeros(0, dtype=int)
+        segs.append([(int(cuts[2 * j]), int(cuts[2 * j + 1])) for j in range(k)])
+    G, cnt = m.segment_sisdr(waves, segs)
+    worst = 0.0
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                assert S[i, i] > 100.0 and np.isfinite(S[i, i])
+                continue
+            worst = max(worst, abs(S[i, j] - si_sdr(a[i], a[j])))
+            for k, (lo, hi) in enumerate(segs[i]):
+                worst = max(worst, abs(G[i, j, k] - si_sdr(a[i, lo:hi], a[j, lo:hi])))
+        assert cnt[i] == len(segs[i]) and np.all(np.isnan(G[i, :, len(segs[i]):]))
+    _log(f"tiled si-sdr n={n} T={T}: worst difference {worst:.2e} dB")
+    assert worst < 1e-3
+
+
 def test_energies_and_sisdr(ops):
     from oracle import spot_ref
     rng = np.random.default_rng(5)
