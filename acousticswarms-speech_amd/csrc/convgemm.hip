@@ -989,7 +989,7 @@ struct ResRows {
 
 template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1), bool GLU = false>
 __global__ __launch_bounds__(64 * WM * WN)
-__attribute__((amdgpu_waves_per_eu(C == 64 ? 4 : WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 ? 2 : (C == 128 ? ASW_RES128_WAVES : 3)) : (C == 64 && WM * WN == 4 ? 4 : 1)))))
+__attribute__((amdgpu_waves_per_eu(C == 64 ? 4 : WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 || (C == 256 && BM == 128) ? 2 : (C == 128 ? ASW_RES128_WAVES : 3)) : (C == 64 && WM * WN == 4 ? 4 : 1)))))
 void resconv16_kernel(const asw_convgemm_args p) {
   static_assert(QD == 2 || QD == 4, "B prefetch depth in k-steps");
   static_assert(!GLU || (C == 64 && PH == 1 && !POLY), "GroupNorm + GLU on load: contiguous C = 64 tiles only");
@@ -1304,7 +1304,13 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
     case 128:
       if (!poly) return launch_res<128, 128, 2, 2, 1, 2>(a, s);
       return rows_per_phase >= 48 ? launch_res<128, 128, 2, 2, 2, 2>(a, s) : launch_res<128, 128, 2, 2, 4, 2>(a, s);
-    case 256: return poly ? launch_res<64, 256, 1, 4, 2, 2>(a, s) : launch_res<64, 256, 1, 4, 1, 2>(a, s);
+    case 256: {
+      // 128-row tiles (wave tile 128 x 64: half the weight-fragment traffic per MFMA, two waves per SIMD
+      // instead of three) once they still fill the chip twice over: 313 -> 335 TFLOP/s at T = 48 000,
+      // batch 64 (same box).  The same step at C = 128 (256-row tiles) loses, 300 -> 292.
+      if (!poly && (long)asw::cdiv(a.M_out, 128) * a.B >= 512) return launch_res<128, 256, 1, 4, 1, 2>(a, s);
+      return poly ? launch_res<64, 256, 1, 4, 2, 2>(a, s) : launch_res<64, 256, 1, 4, 1, 2>(a, s);
+    }
     case 512:
       // polyphase at C = 512 pays only for long phases: 45 rows per phase (T = 144 000) measured 243
       // TFLOP/s against 307 for the contiguous halo image on the same layer shape at T = 48 000
