@@ -1309,6 +1309,8 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
       // instead of three) once they still fill the chip twice over: 313 -> 335 TFLOP/s at T = 48 000,
       // batch 64 (same box).  The same step at C = 128 (256-row tiles) loses, 300 -> 292.
       if (!poly && (long)asw::cdiv(a.M_out, 128) * a.B >= 512) return launch_res<128, 256, 1, 4, 1, 2>(a, s);
+      // (polyphase, two phases of 64 rows: 302 -> 307)
+      if (poly && rows_per_phase >= 48 && (long)asw::cdiv(a.M_out, 128) * a.B >= 512) return launch_res<128, 256, 1, 4, 2, 2>(a, s);
       return poly ? launch_res<64, 256, 1, 4, 2, 2>(a, s) : launch_res<64, 256, 1, 4, 1, 2>(a, s);
     }
     case 512:
