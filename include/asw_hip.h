@@ -247,7 +247,9 @@ int asw_pad_preproc(const float* x, int B, int M, int t, int T_pad, const float*
  * epi: +bias[n]; activation (relu: 0 none, 1 ReLU, 2 Swish x*sigmoid(x)); +resid; *mul; LayerNorm over n (ln_gamma!=NULL,
  * requires N in {64,128,256,512,1024}); group statistics partials (stats!=NULL).
  * Replaces nn.Conv1d / nn.ConvTranspose1d / nn.Linear + ReLU / residual / LayerNorm of
- * network.py:57-68,105-113,190-198 and the transformer linears. */
+ * network.py:57-68,105-113,190-198 and the transformer linears.
+ * Zero-initialise the block (memset / = {}) before filling it: every optional pointer is tested against NULL,
+ * and the struct only ever grows at its end. */
 typedef struct asw_convgemm_args {
   const float* A;         /* [B][a_batch_stride] */
   const float* A2;        /* optional tensor added to A while loading (skip connection) */
