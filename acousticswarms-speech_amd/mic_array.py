@@ -216,6 +216,8 @@ class MicArray(object):
         self._dev_cache = {}               # id(waveform) -> (waveform, its device row)
         if resident and not sharded and n_groups >= 3 and getattr(spot_model, "device", None) is not None:
             return self._fine_stage_pipelined(mix_data, candidate_finished, spot_model, sample_gt, thr_new)
+        if resident and sharded and getattr(inner, "device", None) is not None:
+            return self._fine_stage_sharded(mix_data, candidate_finished, spot_model, sample_gt, thr_new)
 
         total_patch, bounds, areas, centers = [], [0], [], []
         for big in candidate_finished:
@@ -286,17 +288,53 @@ class MicArray(object):
                     self._seg_cache[id(p[1])] = (p[1], t[-1])
         return output_pair
 
-    def _fine_stage_pipelined(self, mix_data, candidate_finished, spot_model, sample_gt, thr_new):
+    def _fine_stage_sharded(self, mix_data, candidate_finished, spot_model, sample_gt, thr_new):
+        """One rank per GPU with the HIP model (shard.ShardedSpotModel): every rank subdivides all coarse
+        patches (the size-balanced deal needs every size), runs the pipelined fine stage on the patches it
+        owns, then the stage's exchanges: the energy all-gather and the object gather of the finished
+        output tuples with their voiced segments.  Same output_pair list on every rank as on one GPU."""
+        n_groups = len(candidate_finished)
+        fines, centres = [], []
+        for big in candidate_finished:
+            fine, c = self._subdivide(big)
+            fines.append(fine)
+            centres.append(c)
+        sizes = [len(f) for f in fines]
+        self.spotforming_times = int(sum(sizes))
+        gbounds = [0]
+        for n in sizes:
+            gbounds.append(gbounds[-1] + n)
+        mine = spot_model.my_groups(sizes)
+        output_pair, energies = self._fine_stage_pipelined(mix_data, candidate_finished, spot_model, sample_gt, thr_new,
+                                                           owned=mine, pre=(fines, centres))
+        self.fine_energies = spot_model.all_gather_groups(energies, mine, gbounds)
+        # the voiced segments of every head travel with its tuple: the global clustering of every rank
+        # then finds them cached for the remote heads too, as it does for its own
+        tagged = [p + (self._seg_cache.get(id(p[1]), (None, None))[1],) for p in output_pair]
+        merged = spot_model.gather_pairs(tagged)
+        output_pair = [t[:-1] for t in merged]
+        for t, p in zip(merged, output_pair):
+            if t[-1] is not None:
+                self._seg_cache[id(p[1])] = (p[1], t[-1])
+        return output_pair
+
+    def _fine_stage_pipelined(self, mix_data, candidate_finished, spot_model, sample_gt, thr_new, owned=None, pre=None):
         """Single-GPU fine stage with the host work hidden behind the GPU: the coarse patches are
-        processed in three contiguous chunks; while the GPU evaluates the candidates of chunk c
+        processed in contiguous chunks; while the GPU evaluates the candidates of chunk c
         the host subdivides the patches of chunk c+1, and the clustering of chunk c (energies,
         Gram launches, head copies -- issued on a side stream that only waits for chunk c) runs
-        while the GPU is already on chunk c+1.  Same candidates, same order, same output."""
+        while the GPU is already on chunk c+1.  Same candidates, same order, same output.
+        ``owned`` (sharded use): the coarse patches this rank owns, already subdivided in ``pre`` =
+        (fines, centres); the call then returns (output_pair, energies of these groups in that order)."""
         import torch
-        dev = spot_model.device
+        dev = getattr(spot_model, "inner", spot_model).device
         mix_dev = torch.as_tensor(mix_data).to(dev, dtype=torch.float32).contiguous()
         T_len = int(mix_dev.shape[1])
-        n_groups = len(candidate_finished)
+        order = list(range(len(candidate_finished))) if owned is None else [int(g) for g in owned]
+        n_groups = len(order)
+        local_energies = []
+        if n_groups == 0:                                  # a rank that was dealt no coarse patch
+            return ([], np.zeros((0, 2))) if owned is not None else []
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=dev)
         side, main = self._side_stream, torch.cuda.current_stream(dev)
@@ -316,6 +354,7 @@ class MicArray(object):
                 waves.record_stream(side)
                 en_dev.record_stream(side)
                 energies = en_dev.cpu().numpy()
+                local_energies.append(energies)
                 pos = 0
                 for g, fine, centre in zip(groups, fines, centres):
                     n = len(fine)
@@ -325,16 +364,19 @@ class MicArray(object):
                     pos += n
 
         for k in range(n_chunks):
-            groups = list(range(edges[k], edges[k + 1]))
+            groups = order[edges[k]:edges[k + 1]]
             if not groups:
                 continue
             fines, centres, flat = [], [], []
             for g in groups:                                   # host: subdivision of this chunk
-                fine, c = self._subdivide(candidate_finished[g])
+                if pre is None:
+                    fine, c = self._subdivide(candidate_finished[g])
+                    self.spotforming_times += len(fine)
+                else:
+                    fine, c = pre[0][g], pre[1][g]
                 fines.append(fine)
                 centres.append(c)
                 flat.extend(fine)
-                self.spotforming_times += len(fine)
             waves, en_dev = spot_model.shift_and_sep_resident(mix_dev, flat, Strict=1, device_energies=True)
             ev = torch.cuda.Event()
             ev.record(main)
@@ -343,6 +385,8 @@ class MicArray(object):
             inflight = (groups, fines, centres, waves, en_dev, ev)
         if inflight is not None:
             finish(inflight)
+        if owned is not None:
+            return output_pair, (np.concatenate(local_energies, axis=0) if local_energies else np.zeros((0, 2)))
         return output_pair
 
     # ---- stage 4: global non-max suppression (sep/Mic_Array.py:399-500) -----------------
