@@ -289,25 +289,24 @@ class MicArray(object):
         return output_pair
 
     def _fine_stage_sharded(self, mix_data, candidate_finished, spot_model, sample_gt, thr_new):
-        """One rank per GPU with the HIP model (shard.ShardedSpotModel): every rank subdivides all coarse
-        patches (the size-balanced deal needs every size), runs the pipelined fine stage on the patches it
-        owns, then the stage's exchanges: the energy all-gather and the object gather of the finished
-        output tuples with their voiced segments.  Same output_pair list on every rank as on one GPU."""
+        """One rank per GPU with the HIP model (shard.ShardedSpotModel).  Whole coarse patches are dealt to
+        ranks by a weight every rank knows without subdividing anything -- the number of 1 cm grid points of
+        the patch, which is what drives the size of its subdivision; each rank then subdivides and runs the
+        pipelined fine stage on ITS patches only.  The stage's exchanges follow: the sizes (a few integers),
+        the energy all-gather, and the object gather of the finished output tuples with their voiced
+        segments.  Same output_pair list on every rank as on one GPU."""
         n_groups = len(candidate_finished)
-        fines, centres = [], []
-        for big in candidate_finished:
-            fine, c = self._subdivide(big)
-            fines.append(fine)
-            centres.append(c)
-        sizes = [len(f) for f in fines]
+        owners = spot_model.deal_groups([max(1, big.area_size()) for big in candidate_finished])
+        mine = owners[spot_model.rank]
+        sizes_mine = {}
+        output_pair, energies = self._fine_stage_pipelined(mix_data, candidate_finished, spot_model, sample_gt, thr_new,
+                                                           owned=mine, sizes_out=sizes_mine)
+        sizes = spot_model.gather_sizes(sizes_mine, n_groups)
         self.spotforming_times = int(sum(sizes))
         gbounds = [0]
         for n in sizes:
             gbounds.append(gbounds[-1] + n)
-        mine = spot_model.my_groups(sizes)
-        output_pair, energies = self._fine_stage_pipelined(mix_data, candidate_finished, spot_model, sample_gt, thr_new,
-                                                           owned=mine, pre=(fines, centres))
-        self.fine_energies = spot_model.all_gather_groups(energies, mine, gbounds)
+        self.fine_energies = spot_model.all_gather_groups(energies, mine, gbounds, owners=owners)
         # the voiced segments of every head travel with its tuple: the global clustering of every rank
         # then finds them cached for the remote heads too, as it does for its own
         tagged = [p + (self._seg_cache.get(id(p[1]), (None, None))[1],) for p in output_pair]
@@ -318,14 +317,14 @@ class MicArray(object):
                 self._seg_cache[id(p[1])] = (p[1], t[-1])
         return output_pair
 
-    def _fine_stage_pipelined(self, mix_data, candidate_finished, spot_model, sample_gt, thr_new, owned=None, pre=None):
+    def _fine_stage_pipelined(self, mix_data, candidate_finished, spot_model, sample_gt, thr_new, owned=None, sizes_out=None):
         """Single-GPU fine stage with the host work hidden behind the GPU: the coarse patches are
         processed in contiguous chunks; while the GPU evaluates the candidates of chunk c
         the host subdivides the patches of chunk c+1, and the clustering of chunk c (energies,
         Gram launches, head copies -- issued on a side stream that only waits for chunk c) runs
         while the GPU is already on chunk c+1.  Same candidates, same order, same output.
-        ``owned`` (sharded use): the coarse patches this rank owns, already subdivided in ``pre`` =
-        (fines, centres); the call then returns (output_pair, energies of these groups in that order)."""
+        ``owned`` (sharded use): the coarse patches this rank owns; the call then returns (output_pair,
+        energies of these groups in that order) and reports their subdivision sizes in ``sizes_out``."""
         import torch
         dev = getattr(spot_model, "inner", spot_model).device
         mix_dev = torch.as_tensor(mix_data).to(dev, dtype=torch.float32).contiguous()
@@ -369,11 +368,10 @@ class MicArray(object):
                 continue
             fines, centres, flat = [], [], []
             for g in groups:                                   # host: subdivision of this chunk
-                if pre is None:
-                    fine, c = self._subdivide(candidate_finished[g])
-                    self.spotforming_times += len(fine)
-                else:
-                    fine, c = pre[0][g], pre[1][g]
+                fine, c = self._subdivide(candidate_finished[g])
+                self.spotforming_times += len(fine)
+                if sizes_out is not None:
+                    sizes_out[int(g)] = len(fine)
                 fines.append(fine)
                 centres.append(c)
                 flat.extend(fine)

@@ -159,12 +159,32 @@ class ShardedSpotModel:
     def my_groups(self, sizes):
         return shard_groups(sizes, self.world)[self.rank]
 
-    def all_gather_groups(self, local_energies, mine, bounds):
+    def deal_groups(self, weights):
+        """Owners of whole coarse patches from a weight every rank can compute WITHOUT subdividing them
+        (the number of 1 cm grid points of a patch, which is what drives the size of its subdivision):
+        the same longest-processing-time deal as ``my_groups``.  Returns the group indices per rank."""
+        return shard_groups([int(w) for w in weights], self.world)
+
+    def gather_sizes(self, local_sizes: dict, n_groups: int):
+        """{coarse patch: number of fine candidates} of the patches each rank subdivided -> the full list."""
+        box = [None] * self.world
+        self.dist.all_gather_object(box, dict(local_sizes), group=self.group)
+        sizes = [None] * n_groups
+        for part in box:
+            for g, n in part.items():
+                sizes[int(g)] = int(n)
+        if any(v is None for v in sizes):
+            raise RuntimeError("fine-stage sizes: some coarse patch was subdivided by no rank")
+        return sizes
+
+    def all_gather_groups(self, local_energies, mine, bounds, owners=None):
         """All-gather of the fine-stage energies: local rows are this rank's groups in
-        ``mine`` order; returns the full [N,2] table in the global candidate order."""
+        ``mine`` order; returns the full [N,2] table in the global candidate order.  ``owners``:
+        the deal that was used (default: the size-balanced one of ``my_groups``)."""
         import torch
         sizes = [bounds[i + 1] - bounds[i] for i in range(len(bounds) - 1)]
-        owners = shard_groups(sizes, self.world)
+        if owners is None:
+            owners = shard_groups(sizes, self.world)
         width = max(1, max(sum(sizes[g] for g in o) for o in owners))
         import zlib
         assert_same_on_all_ranks(self.dist, self.group, self.device, "fine-stage energy", len(sizes), int(bounds[-1]),
