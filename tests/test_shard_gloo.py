@@ -239,3 +239,51 @@ def test_diverging_candidate_lists_raise_on_every_rank():
         assert p.exitcode == 0
     for _rank, msg in res:
         assert "ranks disagree" in msg
+
+
+def _deal_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from acousticswarms_speech_amd.shard import ShardedSpotModel
+
+        class _Inner:                                     # only the plumbing of the wrapper is exercised
+            pass
+        sm = ShardedSpotModel(_Inner(), device="cpu")
+        weights = [900, 120, 4000, 333, 50, 2100, 7]      # 1 cm grid points of seven coarse patches
+        true_sizes = [31, 12, 38, 20, 12, 35, 12]         # what subdividing them would give
+        owners = sm.deal_groups(weights)
+        mine = owners[rank]
+        sizes = sm.gather_sizes({g: true_sizes[g] for g in mine}, len(weights))
+        bounds = [0]
+        for n in sizes:
+            bounds.append(bounds[-1] + n)
+        local = np.concatenate([np.stack([np.full(true_sizes[g], g + 0.5), np.arange(true_sizes[g], dtype=np.float64)], 1)
+                                for g in mine]) if mine else np.zeros((0, 2))
+        full = sm.all_gather_groups(local, mine, bounds, owners=owners)
+        q.put((rank, owners, sizes, full))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weight_dealt_groups_sizes_and_energy_gather():
+    """The fine stage of one rank per GPU: coarse patches dealt by a weight known without subdividing them
+    (deal_groups), the sizes of the subdivisions exchanged afterwards (gather_sizes), and the energy all-gather
+    assembled with that deal (all_gather_groups(owners=...)): every rank ends with the same full table in the
+    global candidate order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_deal_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, owners0, sizes0, full0), (_, owners1, sizes1, full1) = res
+    assert owners0 == owners1 and sorted(owners0[0] + owners0[1]) == list(range(7))
+    assert sizes0 == sizes1 == [31, 12, 38, 20, 12, 35, 12]
+    np.testing.assert_array_equal(full0, full1)
+    want = np.concatenate([np.stack([np.full(n, g + 0.5), np.arange(n, dtype=np.float64)], 1) for g, n in enumerate(sizes0)])
+    np.testing.assert_array_equal(full0, want)
