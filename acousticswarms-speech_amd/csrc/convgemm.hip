@@ -104,7 +104,7 @@ floatx16 (&acc)[BM / WM / 32][BN / WN / 32], const asw_convgemm_args& p,
   const int b = tile.z, n0 = tile.y * BN;
   float st0 = 0.f, sq0 = 0.f, st1 = 0.f, sq1 = 0.f;
   const int half_mod = p.chan_mod >> 1;
-  const bool guard = !LN && !STATS && p.precision == 1;       // un-normalised output that a later f16x3 GEMM may read
+  const bool guard = !LN && !STATS && p.precision >= 1;       // un-normalised output that a later f16 GEMM may read
   float amax = 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -384,6 +384,24 @@ __device__ __forceinline__ void split4(const float4 x, half4& hi, half4& lo) {
   lo = ul.h;
 }
 
+// Single-pass f16 mode (precision 2: one MFMA per product, the hi halves only): the hi half is rounded to
+// nearest instead of truncated -- with no lo half to catch the remainder, truncation would bias every
+// product low by ~2^-12.  lo is still produced (the C = 64 residual layer reads its residual from the image).
+__device__ __forceinline__ void split4_rn(const float4 x, half4& hi, half4& lo) {
+  const _Float16 h0 = (_Float16)x.x, h1 = (_Float16)x.y, h2 = (_Float16)x.z, h3 = (_Float16)x.w;
+  const fp16x2 l01 = __builtin_amdgcn_cvt_pkrtz(x.x - (float)h0, x.y - (float)h1);
+  const fp16x2 l23 = __builtin_amdgcn_cvt_pkrtz(x.z - (float)h2, x.w - (float)h3);
+  hi = half4{h0, h1, h2, h3};
+  union { fp16x2 v[2]; half4 h; } ul;
+  ul.v[0] = l01; ul.v[1] = l23;
+  lo = ul.h;
+}
+template <int NTERM>
+__device__ __forceinline__ void split4t(const float4 x, half4& hi, half4& lo) {
+  if constexpr (NTERM == 1) split4_rn(x, hi, lo);
+  else split4(x, hi, lo);
+}
+
 // Four-wave tiles whose LDS footprint lets three workgroups share a CU get a register budget for
 // three waves per SIMD (hipcc otherwise spends ~180 VGPRs -> two): these are the small-K, write- and
 // latency-bound layers, which gain from the third resident workgroup (128x128 tiles: strided conv
@@ -400,7 +418,7 @@ constexpr int g16_waves_per_eu() {
   if (WM * WN == 4 && (stage > slab ? stage : slab) <= 80 * 1024 && (stage > slab ? stage : slab) > 53 * 1024) return 2;
   return (WM * WN == 4 && (stage > slab ? stage : slab) <= 53 * 1024) ? 3 : 1;
 }
-template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL, bool A2F>
+template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL, bool A2F, int NTERM = 3>
 __global__ __launch_bounds__(64 * WM * WN)
 __attribute__((amdgpu_waves_per_eu(g16_waves_per_eu<BM, BN, BK, WM, WN>())))
 void convgemm16_kernel(const asw_convgemm_args p) {
@@ -486,7 +504,7 @@ void convgemm16_kernel(const asw_convgemm_args p) {
     for (int v = 0; v < B_VEC; ++v) {
       const long o = (b_ok[v] ? b_row[v] : 0) + (long)kc * BK;
       rbh[v] = *reinterpret_cast<const half8*>(Wh + o);   // rows past BN*KH are never stored to LDS
-      rbl[v] = *reinterpret_cast<const half8*>(Wl + o);
+      if (NTERM == 3) rbl[v] = *reinterpret_cast<const half8*>(Wl + o);
     }
   };
   auto lstore = [&](const float4 (&ra)[A_VEC], const half8 (&rbh)[B_VEC], const half8 (&rbl)[B_VEC]) {
@@ -496,9 +514,9 @@ void convgemm16_kernel(const asw_convgemm_args p) {
       const int row = idx / KV, cv = idx - row * KV;
       if (idx < BM * KV) {
         half4 hi, lo;
-        split4(ra[v], hi, lo);
+        split4t<NTERM>(ra[v], hi, lo);
         *reinterpret_cast<half4*>(Ah + row * LDH + cv * 4) = hi;
-        *reinterpret_cast<half4*>(Al + row * LDH + cv * 4) = lo;
+        if (NTERM == 3) *reinterpret_cast<half4*>(Al + row * LDH + cv * 4) = lo;
       }
     }
 #pragma unroll
@@ -507,7 +525,7 @@ void convgemm16_kernel(const asw_convgemm_args p) {
       const int row = idx / KH, cv = idx - row * KH;
       if (idx < BN * KH) {
         *reinterpret_cast<half8*>(Bh + row * LDH + cv * 8) = rbh[v];
-        *reinterpret_cast<half8*>(Bl + row * LDH + cv * 8) = rbl[v];
+        if (NTERM == 3) *reinterpret_cast<half8*>(Bl + row * LDH + cv * 8) = rbl[v];
       }
     }
   };
@@ -530,19 +548,21 @@ void convgemm16_kernel(const asw_convgemm_args p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const half8*>(Ah + a_off + i * 32 * LDH + ks * 16);
-        al[i] = *reinterpret_cast<const half8*>(Al + a_off + i * 32 * LDH + ks * 16);
+        if (NTERM == 3) al[i] = *reinterpret_cast<const half8*>(Al + a_off + i * 32 * LDH + ks * 16);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = *reinterpret_cast<const half8*>(Bh + b_off + j * 32 * LDH + ks * 16);
-        bl[j] = *reinterpret_cast<const half8*>(Bl + b_off + j * 32 * LDH + ks * 16);
+        if (NTERM == 3) bl[j] = *reinterpret_cast<const half8*>(Bl + b_off + j * 32 * LDH + ks * 16);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if (NTERM == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -605,7 +625,7 @@ void convgemm16_kernel(const asw_convgemm_args p) {
 // Main loop of one 256-column tile: picks the tile of this workgroup (false: none, the whole workgroup
 // leaves), runs the K loop and returns the accumulators (wave (wm, wn) of 2 x 4 holds rows
 // wm*BM/2 + 32*i.., columns wn*64 + 32*j..).  Ends on a barrier: the ring is free for the epilogue.
-template <int BM, bool A2F, int BK>
+template <int BM, bool A2F, int BK, int NTERM = 3>
 __device__ __forceinline__ bool pipe_mainloop(const asw_convgemm_args& p, float* smem, floatx16 (&acc)[BM / 64][2],
                                               dim3& tile_out, int& ncol_out) {
   constexpr int BN = 256, WM = 2, WN = 4, NT = 512, QDB = ASW_PIPE_QDB;
@@ -672,9 +692,9 @@ __device__ __forceinline__ bool pipe_mainloop(const asw_convgemm_args& p, float*
       const int row = idx / KV, cv = idx - row * KV;
       if (idx < BM * KV) {
         half4 hi, lo;
-        split4(ra[v], hi, lo);
+        split4t<NTERM>(ra[v], hi, lo);
         *reinterpret_cast<half4*>(Ah + row * LDH + cv * 4) = hi;
-        *reinterpret_cast<half4*>(Al + row * LDH + cv * 4) = lo;
+        if (NTERM == 3) *reinterpret_cast<half4*>(Al + row * LDH + cv * 4) = lo;
       }
     }
   };
@@ -683,7 +703,7 @@ __device__ __forceinline__ bool pipe_mainloop(const asw_convgemm_args& p, float*
     for (int j = 0; j < TN; ++j) {
       const long o = ((long)kg * NTF + nt0 + j) * 64 + lane;
       bh[j] = Wh[o];
-      bl[j] = Wl[o];
+      if (NTERM == 3) bl[j] = Wl[o];
     }
   };
 
@@ -717,15 +737,17 @@ __device__ __forceinline__ bool pipe_mainloop(const asw_convgemm_args& p, float*
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const half8*>(Ah + a_off + i * 32 * LDH + ks * 16);
-        al[i] = *reinterpret_cast<const half8*>(Al + a_off + i * 32 * LDH + ks * 16);
+        if (NTERM == 3) al[i] = *reinterpret_cast<const half8*>(Al + a_off + i * 32 * LDH + ks * 16);
       }
       const int q = (PAR * KS + ks) % QDB;         // B register buffer of this k-step
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], qh[q][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], ql[q][j], acc[i][j], 0, 0, 0);
+          if (NTERM == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], qh[q][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], ql[q][j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], qh[q][j], acc[i][j], 0, 0, 0);
         }
       const int kg = kc * KS + ks + QDB;           // same slot, QDB k-steps ahead
@@ -744,7 +766,7 @@ __device__ __forceinline__ bool pipe_mainloop(const asw_convgemm_args& p, float*
   return true;
 }
 
-template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32>
+template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32, int NTERM = 3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void convgemm16p_kernel(const asw_convgemm_args p) {
   constexpr int BN = 256, WM = 2, WN = 4;
@@ -752,7 +774,7 @@ void convgemm16p_kernel(const asw_convgemm_args p) {
   floatx16 acc[BM / 64][2];
   dim3 tile;
   int ncol;
-  if (!pipe_mainloop<BM, A2F, BK>(p, smem, acc, tile, ncol)) return;
+  if (!pipe_mainloop<BM, A2F, BK, NTERM>(p, smem, acc, tile, ncol)) return;
   epilogue<BM, BN, WM, WN, false, STATS, false, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
                                                      RowsContig{(int)tile.x * BM, p.M_out}, tile, ncol);
 }
@@ -771,7 +793,7 @@ void convgemm16p_kernel(const asw_convgemm_args p) {
 //     column tile's share of the sum over e); the overlap-add kernel adds the N/256 partials.
 // Per candidate (T = 48 000) this writes 8 x 3008 x 33 floats instead of writing the bypass latent,
 // reading it, writing the gated latent and reading that again (4 x 24.6 MB).
-template <int BM, int KSB>
+template <int BM, int KSB, int NTERM = 3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void maskpath16p_kernel(const asw_convgemm_args p, const asw_maskpath_args mf) {
   constexpr int BN = 256, WN = 4, TM = BM / 64, TN = 2, LDC = BN + 4, BK = 32;
@@ -780,7 +802,7 @@ void maskpath16p_kernel(const asw_convgemm_args p, const asw_maskpath_args mf) {
   floatx16 acc[TM][TN];
   dim3 tile;
   int ncol;
-  if (!pipe_mainloop<BM, false, BK>(p, smem, acc, tile, ncol)) return;
+  if (!pipe_mainloop<BM, false, BK, NTERM>(p, smem, acc, tile, ncol)) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int b = tile.z, m0 = tile.x * BM, n0 = tile.y * BN;
@@ -815,12 +837,14 @@ void maskpath16p_kernel(const asw_convgemm_args p, const asw_maskpath_args mf) {
         const long e = (long)f * mf.ref_hop + ks * 16 + (lane >> 5) * 8;
         const float4 x0 = act_load4(rR, e, ok), x1 = act_load4(rR, e + 4, ok);
         half4 h0, l0, h1, l1;
-        split4(x0, h0, l0);
-        split4(x1, h1, l1);
+        split4t<NTERM>(x0, h0, l0);
+        split4t<NTERM>(x1, h1, l1);
         const half8 ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
         const half8 al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-        bp = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[ks], bp, 0, 0, 0);
-        bp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[ks], bp, 0, 0, 0);
+        if (NTERM == 3) {
+          bp = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[ks], bp, 0, 0, 0);
+          bp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[ks], bp, 0, 0, 0);
+        }
         bp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[ks], bp, 0, 0, 0);
       }
 #pragma unroll
@@ -867,12 +891,14 @@ void maskpath16p_kernel(const asw_convgemm_args p, const asw_maskpath_args mf) {
       const long o = ((long)(n0 / 16 + ks) * 2 + tt) * 64 + lane;
       const half8 dh = Dh[o], dl = Dl[o];
       half4 h0, l0, h1, l1;
-      split4(x0, h0, l0);
-      split4(x1, h1, l1);
+      split4t<NTERM>(x0, h0, l0);
+      split4t<NTERM>(x1, h1, l1);
       const half8 ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
       const half8 al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-      tp = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, dh, tp, 0, 0, 0);
-      tp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dl, tp, 0, 0, 0);
+      if (NTERM == 3) {
+        tp = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, dh, tp, 0, 0, 0);
+        tp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dl, tp, 0, 0, 0);
+      }
       tp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dh, tp, 0, 0, 0);
     }
     const int j = tt * 32 + (lane & 31);
@@ -903,15 +929,17 @@ int launch_mask_path(const asw_maskpath_args* args, void* stream) {
                 "mask_path: decoder taps 1..64, reference hop a multiple of 4 samples");
   ASW_CHECK_ARG((reinterpret_cast<uintptr_t>(m.ref) & 15) == 0 && m.ref_batch_stride % 4 == 0,
                 "mask_path: reference rows must be 16-byte aligned");
-  a.precision = 1;
+  ASW_CHECK_ARG(a.precision == 1 || a.precision == 2, "mask_path: precision 1 (f16x3) or 2 (single-pass f16)");
+  const bool x1 = a.precision == 2;
   a.relu = 1;
   constexpr size_t ring = (size_t)2 * 2 * BM * (BK + 8) * sizeof(_Float16);
   constexpr size_t slab = (size_t)128 * (BN + 4) * sizeof(float);
   constexpr size_t smem = ring > slab ? ring : slab;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  const void* kern = reinterpret_cast<const void*>(maskpath16p_kernel<BM, KSB>);
-  static asw::SmemAttr attr;                            // per device
-  if (int rc = attr.ensure(kern, smem)) return rc;
+  const void* kern = x1 ? reinterpret_cast<const void*>(maskpath16p_kernel<BM, KSB, 1>)
+                        : reinterpret_cast<const void*>(maskpath16p_kernel<BM, KSB, 3>);
+  static asw::SmemAttr attr[2];                         // per device and instantiation
+  if (int rc = attr[x1].ensure(kern, smem)) return rc;
   const long nrt = asw::cdiv(a.M_out, BM);
   dim3 grid(((nrt * a.B + 7) / 8) * 8 * (a.N / BN), 1, 1);
   std::string pn = "maskpath16p<256,256,32>";
@@ -922,7 +950,8 @@ int launch_mask_path(const asw_maskpath_args* args, void* stream) {
   }
   // mask encoder + bypass + decoder taps
   asw::ProfScope prof(s, pn, 2.0 * a.B * (double)a.M_out * a.N * ((double)a.taps * a.Cin + m.byp_taps + m.dec_taps));
-  hipLaunchKernelGGL((maskpath16p_kernel<BM, KSB>), grid, dim3(512), smem, s, a, m);
+  if (x1) hipLaunchKernelGGL((maskpath16p_kernel<BM, KSB, 1>), grid, dim3(512), smem, s, a, m);
+  else hipLaunchKernelGGL((maskpath16p_kernel<BM, KSB, 3>), grid, dim3(512), smem, s, a, m);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }
@@ -934,9 +963,11 @@ int launch_pipe(const asw_convgemm_args& a, hipStream_t s) {
   constexpr size_t slab = (size_t)(2 * 32) * (BN + 4) * sizeof(float);
   constexpr size_t smem = ring > slab ? ring : slab;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  const void* kern = reinterpret_cast<const void*>(convgemm16p_kernel<BM, STATS, MUL, A2F, BK>);
-  static asw::SmemAttr attr;                            // per device
-  if (int rc = attr.ensure(kern, smem)) return rc;
+  const bool x1 = a.precision == 2;                     // single-pass f16: the one-term instantiation
+  const void* kern = x1 ? reinterpret_cast<const void*>(convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 1>)
+                        : reinterpret_cast<const void*>(convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 3>);
+  static asw::SmemAttr attr[2];                         // per device and instantiation
+  if (int rc = attr[x1].ensure(kern, smem)) return rc;
   ASW_CHECK_ARG(A2F == (a.A2 != nullptr), "convgemm: skip operand variant mismatch");
   ASW_CHECK_ARG(a.Cin % BK == 0 && a.N % BN == 0, "convgemm: pipelined tile needs Cin %% BK == 0 and N %% 256 == 0");
   const long nrt = asw::cdiv(a.M_out, BM);
@@ -948,7 +979,8 @@ int launch_pipe(const asw_convgemm_args& a, hipStream_t s) {
     pn += sh;
   }
   asw::ProfScope prof(s, pn, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
-  hipLaunchKernelGGL((convgemm16p_kernel<BM, STATS, MUL, A2F, BK>), grid, dim3(512), smem, s, a);
+  if (x1) hipLaunchKernelGGL((convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 1>), grid, dim3(512), smem, s, a);
+  else hipLaunchKernelGGL((convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 3>), grid, dim3(512), smem, s, a);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }
@@ -987,7 +1019,7 @@ struct ResRows {
   }
 };
 
-template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1), bool GLU = false>
+template <int BM, int C, int WM, int WN, int PH, int QD = 4, bool POLY = (PH > 1), bool GLU = false, int NTERM = 3>
 __global__ __launch_bounds__(64 * WM * WN)
 __attribute__((amdgpu_waves_per_eu(C == 64 ? 4 : WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 || (C == 256 && BM == 128) ? 2 : (C == 128 ? ASW_RES128_WAVES : 3)) : (C == 64 && WM * WN == 4 ? 4 : 1)))))
 void resconv16_kernel(const asw_convgemm_args p) {
@@ -1101,9 +1133,9 @@ void resconv16_kernel(const asw_convgemm_args p) {
         const int row = r0 + u * SROWS + srow;
         if (row < R) {
           half4 hi, lo;
-          split4(buf[u], hi, lo);
+          split4t<NTERM>(buf[u], hi, lo);
           *reinterpret_cast<half4*>(img + row * RS + sc4 * 8) = hi;
-          *reinterpret_cast<half4*>(img + row * RS + 128 + sc4 * 8) = lo;
+          if (NTERM == 3 || C == 64) *reinterpret_cast<half4*>(img + row * RS + 128 + sc4 * 8) = lo;
         }
       }
     }
@@ -1115,7 +1147,7 @@ void resconv16_kernel(const asw_convgemm_args p) {
       for (int j = 0; j < TN; ++j) {
         const long o = (kg * NT + nt0 + j) * 64 + lane;
         bh[j] = Wh[o];
-        bl[j] = Wl[o];
+        if (NTERM == 3) bl[j] = Wl[o];
       }
     };
     // A fragments are double buffered in registers, one k-step ahead: left to itself the compiler
@@ -1127,7 +1159,7 @@ void resconv16_kernel(const asw_convgemm_args p) {
       for (int i = 0; i < TM; ++i) {
         const char* q = img + a_base[i] + tap * tapstep * RS + ks * 32;
         ah[i] = *reinterpret_cast<const half8*>(q);
-        al[i] = *reinterpret_cast<const half8*>(q + 128);
+        if (NTERM == 3) al[i] = *reinterpret_cast<const half8*>(q + 128);
       }
     };
     auto mma = [&](const half8 (&ah)[TM], const half8 (&al)[TM], const half8 (&bh)[TN], const half8 (&bl)[TN]) {
@@ -1135,8 +1167,10 @@ void resconv16_kernel(const asw_convgemm_args p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if (NTERM == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
@@ -1233,9 +1267,10 @@ int launch_res(const asw_convgemm_args& a, hipStream_t s) {
   const size_t slab = (size_t)(WM * 32) * (C + 4) * sizeof(float);
   const size_t smem = img > slab ? img : slab;
   if (smem > 160 * 1024) return 1;                     // caller falls back to the generic kernel
-  auto kern = resconv16_kernel<BM, C, WM, WN, PH, QD, POLY, GLU>;
-  static asw::SmemAttr attr;                            // per device
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
+  const bool x1 = a.precision == 2;                     // single-pass f16: the one-term instantiation
+  auto kern = x1 ? resconv16_kernel<BM, C, WM, WN, PH, QD, POLY, GLU, 1> : resconv16_kernel<BM, C, WM, WN, PH, QD, POLY, GLU, 3>;
+  static asw::SmemAttr attr[2];                         // per device and instantiation
+  if (int rc = attr[x1].ensure(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
   const int gx = !POLY ? asw::cdiv(a.M_out, BM)
                        : asw::cdiv(asw::cdiv(a.M_out, a.dil), BMJ) * asw::cdiv(a.dil, PH);
   dim3 grid(gx, 1, a.B);
@@ -1252,7 +1287,7 @@ int launch_res(const asw_convgemm_args& a, hipStream_t s) {
 
 // returns 1 when the layer is not a halo-kernel case (or does not fit LDS)
 int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
-  const bool shape = a.precision == 1 && a.Wf_hi && a.Wf_lo && a.ln_gamma && a.stride == 1 && a.taps > 1 &&
+  const bool shape = a.precision >= 1 && a.Wf_hi && a.Wf_lo && a.ln_gamma && a.stride == 1 && a.taps > 1 &&
                      a.taps % 2 == 1 && a.Cin == a.N && a.a_row_stride == a.Cin && a.resid == a.A && !a.A2 &&
                      !a.mul && !a.stats && a.pad * 2 == (a.taps - 1) * a.dil &&
                      a.a_len == (int64_t)a.M_out * a.Cin && a.a_batch_stride == a.a_len;
@@ -1329,11 +1364,14 @@ int launch(const asw_convgemm_args& a, hipStream_t s) {
   constexpr size_t slab = (size_t)(WM * 32) * (BN + 4) * sizeof(float);
   constexpr size_t smem = stage > slab ? stage : slab;
   static_assert(smem <= 160 * 1024, "LDS budget");
+  const bool x1 = F16 && a.precision == 2;              // single-pass f16: the one-term instantiation
   const void* kern;
-  if constexpr (F16) kern = reinterpret_cast<const void*>(convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>);
+  if constexpr (F16)
+    kern = x1 ? reinterpret_cast<const void*>(convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F, 1>)
+              : reinterpret_cast<const void*>(convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F, 3>);
   else kern = reinterpret_cast<const void*>(convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>);
-  static asw::SmemAttr attr;                            // per device
-  if (int rc = attr.ensure(kern, smem)) return rc;
+  static asw::SmemAttr attr[2];                         // per device and instantiation
+  if (int rc = attr[x1].ensure(kern, smem)) return rc;
   ASW_CHECK_ARG(A2F == (a.A2 != nullptr), "convgemm: the skip operand is fused only in the 128-wide statistics tile");
   ASW_CHECK_ARG(a.Cin % BK == 0, "convgemm: Cin=%d not a multiple of BK=%d", a.Cin, BK);
   ASW_CHECK_ARG(a.N % BN == 0, "convgemm: N=%d not a multiple of BN=%d", a.N, BN);
@@ -1347,9 +1385,10 @@ int launch(const asw_convgemm_args& a, hipStream_t s) {
     pn += sh;
   }
   asw::ProfScope prof(s, pn, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
-  if constexpr (F16)
-    hipLaunchKernelGGL((convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>), grid, dim3(64 * WM * WN), smem, s, a);
-  else
+  if constexpr (F16) {
+    if (x1) hipLaunchKernelGGL((convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F, 1>), grid, dim3(64 * WM * WN), smem, s, a);
+    else hipLaunchKernelGGL((convgemm16_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F, 3>), grid, dim3(64 * WM * WN), smem, s, a);
+  } else
     hipLaunchKernelGGL((convgemm_kernel<BM, BN, BK, WM, WN, LN, STATS, MUL, A2F>), grid, dim3(256), smem, s, a);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
@@ -1357,7 +1396,7 @@ int launch(const asw_convgemm_args& a, hipStream_t s) {
 
 template <int BM, int BN, int BK, int WM, int WN, bool LN, bool STATS, bool MUL = false>
 int launch_prec(const asw_convgemm_args& a, hipStream_t s) {
-  return a.precision == 1 ? launch<BM, BN, BK, WM, WN, LN, STATS, MUL, true>(a, s)
+  return a.precision >= 1 ? launch<BM, BN, BK, WM, WN, LN, STATS, MUL, true>(a, s)
                           : launch<BM, BN, BK, WM, WN, LN, STATS, MUL, false>(a, s);
 }
 
@@ -1479,8 +1518,8 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
     ASW_HIP(hipMemsetAsync(a.stats, 0, (size_t)a.B * a.stats_stride * 4 * sizeof(float), s));
   }
   ASW_CHECK_ARG(a.A && a.out, "convgemm: null tensor");
-  ASW_CHECK_ARG(a.precision == 0 || a.precision == 1, "convgemm: precision %d", a.precision);
-  if (a.precision == 1) ASW_CHECK_ARG(a.Wt_hi && a.Wt_lo, "convgemm: f16x3 needs Wt_hi/Wt_lo");
+  ASW_CHECK_ARG(a.precision >= 0 && a.precision <= 2, "convgemm: precision %d", a.precision);
+  if (a.precision >= 1) ASW_CHECK_ARG(a.Wt_hi && a.Wt_lo, "convgemm: the f16 modes need Wt_hi/Wt_lo");
   else ASW_CHECK_ARG(a.Wt != nullptr, "convgemm: null weights");
   ASW_CHECK_ARG(a.B > 0 && a.M_out > 0 && a.N > 0 && a.Cin > 0 && a.taps > 0, "convgemm: bad dims");
   ASW_CHECK_ARG(a.a_len > 0 && a.a_len < (int64_t)1 << 29, "convgemm: a_len=%lld per batch item exceeds the 2 GiB buffer descriptor",
@@ -1514,7 +1553,7 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
   }
   ASW_CHECK_ARG(!a.glu_raw, "convgemm: GroupNorm + GLU on load belongs to a residual layer (LayerNorm + residual)");
   if (wide_tile(a.N)) {
-    if (a.precision == 1) {
+    if (a.precision >= 1) {
       // f16x3 is bound by the bytes each CU can pull per cycle, so take the largest tile the
       // shape fills: 256x256 (8 waves, 1/32 B per MAC), 256x128, else 128x128 (1/16 B per MAC)
       const int t = wide_tile_kind(a.B, a.M_out, a.N, a.taps * a.Cin);
@@ -1547,7 +1586,7 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
     }
     if (a.mul) return launch_prec<128, 128, 32, 2, 2, false, false, true>(a, s);
     if (stats && a.A2)
-      return a.precision == 1 ? launch<128, 128, 32, 2, 2, false, true, false, true, true>(a, s)
+      return a.precision >= 1 ? launch<128, 128, 32, 2, 2, false, true, false, true, true>(a, s)
                               : launch<128, 128, 32, 2, 2, false, true, false, false, true>(a, s);
     return stats ? launch_prec<128, 128, 32, 2, 2, false, true>(a, s) : launch_prec<128, 128, 32, 2, 2, false, false>(a, s);
   }

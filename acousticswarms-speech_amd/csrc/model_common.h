@@ -152,7 +152,7 @@ struct GluSrc { const float* raw; const float* mr; const float* gamma; const flo
 
 // f16x3, 64 channels, first layer of dilation 1 with fragment-order weights: the layer that can do it
 inline bool glu_on_load_ok(const std::vector<ResLayer>& res, int prec, int ch) {
-  return prec == 1 && ch == 64 && !res.empty() && res[0].dil == 1 && res[0].wt.fhi && res[0].wt.flo;
+  return prec >= 1 && ch == 64 && !res.empty() && res[0].dil == 1 && res[0].wt.fhi && res[0].wt.flo;
 }
 
 inline int run_res(const std::vector<ResLayer>& res, int prec, int B, int T, int ch, int K, float* x, float* p, float* q,

@@ -195,7 +195,7 @@ struct Plan {
 // The one-launch mask path (asw_mask_path_f16x3) applies in f16x3 mode when the shapes fit its tiles.
 bool fused_mask_path(const asw_sep* m) {
   const asw_sep_config& c = m->cfg;
-  return m->precision == 1 && c.encoder_channels % 256 == 0 && c.channels % 32 == 0 && c.encoder_kernel_size <= 48 &&
+  return m->precision >= 1 && c.encoder_channels % 256 == 0 && c.channels % 32 == 0 && c.encoder_kernel_size <= 48 &&
          c.encoder_stride % 4 == 0 && m->byp_wt48.fhi && m->dec_wt.fhi && m->mask_wt.fhi;
 }
 
@@ -401,7 +401,7 @@ int run_network(asw_sep* m, Plan& pl, const float* mean, const float* stdv, floa
   if (fused_mask_path(m)) {
     asw_maskpath_args f = {};
     asw_convgemm_args& a = f.enc;
-    a.A = x; m->mask_wt.bind(a, 1); a.bias = m->mask_b.p;
+    a.A = x; m->mask_wt.bind(a, m->precision); a.bias = m->mask_b.p;
     a.B = B; a.M_out = pl.F; a.N = E; a.Cin = c.channels; a.taps = EK; a.stride = ES; a.dil = 1; a.pad = EK / 2;
     a.a_row_stride = c.channels; a.a_batch_stride = (int64_t)pl.Tp * c.channels; a.a_len = a.a_batch_stride;
     f.ref = pl.refn; f.ref_batch_stride = pl.RL; f.ref_len = pl.RL; f.ref_hop = ES;
@@ -497,7 +497,7 @@ extern "C" int asw_sep_create(const asw_sep_config* cfg, asw_sep** out) {
 extern "C" void asw_sep_destroy(asw_sep* m) { delete m; }
 
 extern "C" int asw_sep_set_precision(asw_sep* m, int precision) {
-  ASW_CHECK_ARG(m && (precision == 0 || precision == 1), "sep_set_precision: 0 (f32) or 1 (f16x3)");
+  ASW_CHECK_ARG(m && (precision >= 0 && precision <= 2), "sep_set_precision: 0 (f32), 1 (f16x3) or 2 (single-pass f16)");
   m->precision = precision;
   return ASW_OK;
 }

@@ -211,7 +211,7 @@ int get_gates(asw_spot* m, float w0, float w1, GateSet** out) {
 // The one-launch mask path (asw_mask_path_f16x3) applies in f16x3 mode when the shapes fit its tiles.
 bool fused_mask_path(const asw_spot* m) {
   const asw_spot_config& c = m->cfg;
-  return m->fuse_mask && m->precision == 1 && c.encoder_channels % 256 == 0 && c.channels % 32 == 0 &&
+  return m->fuse_mask && m->precision >= 1 && c.encoder_channels % 256 == 0 && c.channels % 32 == 0 &&
          c.encoder_kernel_size <= 48 && c.encoder_stride % 4 == 0 && m->byp_wt48.fhi && m->dec_wt.fhi && m->mask_wt.fhi;
 }
 
@@ -361,7 +361,7 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
   if (fused_mask_path(m)) {
     asw_maskpath_args f = {};
     asw_convgemm_args& a = f.enc;
-    a.A = x; m->mask_wt.bind(a, 1); a.bias = m->mask_b.p;
+    a.A = x; m->mask_wt.bind(a, m->precision); a.bias = m->mask_b.p;
     a.B = B; a.M_out = pl.F; a.N = E; a.Cin = c.channels; a.taps = EK; a.stride = ES; a.dil = 1; a.pad = EK / 2;
     a.a_row_stride = c.channels; a.a_batch_stride = (int64_t)pl.Tp * c.channels; a.a_len = a.a_batch_stride;
     f.ref = pl.refn; f.ref_batch_stride = pl.RL; f.ref_len = pl.RL; f.ref_hop = ES;
@@ -460,7 +460,7 @@ extern "C" int asw_spot_create(const asw_spot_config* cfg, asw_spot** out) {
 extern "C" void asw_spot_destroy(asw_spot* m) { delete m; }
 
 extern "C" int asw_spot_set_precision(asw_spot* m, int precision) {
-  ASW_CHECK_ARG(m && (precision == 0 || precision == 1), "set_precision: 0 (f32) or 1 (f16x3)");
+  ASW_CHECK_ARG(m && (precision >= 0 && precision <= 2), "set_precision: 0 (f32), 1 (f16x3) or 2 (single-pass f16)");
   m->precision = precision;
   return ASW_OK;
 }

@@ -55,10 +55,10 @@ def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, re
     if glu is not None:                      # (raw [B][M_out][2N], mr [B][4], gamma [2N], beta [2N]): GroupNorm + GLU on load
         a.glu_raw, a.glu_mr, a.glu_gamma, a.glu_beta = (_f32(t).data_ptr() for t in glu)
     keep = None
-    if precision == "f16x3":
+    if precision in ("f16x3", "f16"):
         hi, lo, shift = split_weights_f16(Wt)
         keep = (hi, lo)
-        a.precision, a.w_shift, a.Wt_hi, a.Wt_lo = 1, shift, hi.data_ptr(), lo.data_ptr()
+        a.precision, a.w_shift, a.Wt_hi, a.Wt_lo = (1 if precision == "f16x3" else 2), shift, hi.data_ptr(), lo.data_ptr()
         if use_fragments and N % 32 == 0 and (taps * Cin) % 16 == 0:
             fh, fl, sh2 = pack_fragments_f16(Wt, N, taps * Cin)
             assert sh2 == shift

@@ -30,7 +30,7 @@ def rounded_offsets(sample_list, n_pairs: int) -> np.ndarray:
 
 
 class SepModel:
-    PRECISIONS = {"f32": 0, "f16x3": 1}
+    PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 2}
 
     def __init__(self, cfg: SepConfig = SEP_FULL, state_dict=None, precision: str = "f32"):
         if precision not in self.PRECISIONS:

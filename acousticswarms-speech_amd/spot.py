@@ -30,7 +30,7 @@ def offsets_from_patches(patch_list, n_pairs: int) -> np.ndarray:
 
 
 class SpotModel:
-    PRECISIONS = {"f32": 0, "f16x3": 1}
+    PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 2}
 
     def __init__(self, cfg: SpotConfig = FULL, state_dict=None, batch_size: int = 32, precision: str = "f32",
                  lanes: int = 1):

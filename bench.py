@@ -323,6 +323,17 @@ def main():
         extras[f"precision_{other}"] = {"value": round(n_total * 2 / dt2, 2), "unit": "candidates/s", "steps": 2,
                                         "note": "same workload, other arithmetic mode of the GEMM-class layers"}
         model.set_precision(args.precision)
+        if args.precision == "f16x3":
+            # the OPTIONAL single-pass f16 mode (one MFMA per product): reduced precision, reported beside the
+            # fp32-class headline, never as it
+            model.set_precision("f16")
+            dt4 = timed(step, 2, 1)
+            extras["precision_f16_single_pass"] = {
+                "value": round(n_total * 2 / dt4, 2), "unit": "candidates/s", "steps": 2,
+                "note": "optional mode, one f16 MFMA per product: 47-48 dB from the reference's outputs (f16x3: 100+), "
+                        "about 2 % of the search's hard decisions change on the seeded random weights "
+                        "(profiles/r2/flip_rate_f16_single_pass.json); not comparable with the fp32-class headline"}
+            model.set_precision(args.precision)
         if T != 144000:
             sc3 = make_scene(WORKLOAD_SEED, n_speakers=WORKLOAD_SPEAKERS, n_mics=7, T=144000, reverb=True)
             mix3 = torch.from_numpy(sc3.mix).to(dev)

@@ -188,7 +188,8 @@ def _count_flips(a, b):
     return {"coarse": coarse, "fine_accept": accept, "fine_membership": members, "final": final}
 
 
-def test_f16x3_flip_rate_full_size(full_weights):
+def _flip_rate(full_weights, mode, seeds, out_name):
+    """The complete search in exact f32 and in `mode` on the given scenes: decision differences and positions."""
     from acousticswarms_speech_amd.config import FULL
     from acousticswarms_speech_amd.joint import JointModel
     from acousticswarms_speech_amd.scenes import make_scene
@@ -198,19 +199,19 @@ def test_f16x3_flip_rate_full_size(full_weights):
     rows, tot = [], {"coarse": 0, "fine_accept": 0, "fine_membership": 0, "final": 0}
     n_coarse = n_fine = 0
     worst_cm = 0.0
-    for seed in list(range(1001, 1009)) + list(range(1010, 1018)):
+    for seed in seeds:
         five = seed >= 1010
         sc = make_scene(seed, 5 if five else 3, 7, 48000, reverb=five)
         mix_t = torch.from_numpy(sc.mix)
         with redirect_stdout(io.StringIO()):
             jm.setup(sc.mic_positions, sc.speaker_range)
         out = {}
-        for prec in ("f32", "f16x3"):
+        for prec in ("f32", mode):
             spot.set_precision(prec)
             patches, audio_loc, _a, spot_times, tr = _search(jm, mix_t)
             assert np.all(np.isfinite(audio_loc)) if len(patches) else True
             out[prec] = (patches, spot_times, tr, jm.Mic_processor.big_spotforming_times)
-        (p32, n32, t32, c32), (p16, n16, t16, _c) = out["f32"], out["f16x3"]
+        (p32, n32, t32, c32), (p16, n16, t16, _c) = out["f32"], out[mode]
         fl = _count_flips(t32, t16)
         n_coarse += c32
         n_fine += n32 - c32
@@ -220,20 +221,37 @@ def test_f16x3_flip_rate_full_size(full_weights):
         for k in tot:
             tot[k] += fl[k]
         rows.append({"seed": seed, "speakers": 5 if five else 3, "reverb": five, "spot_calls_f32": int(n32),
-                     "spot_calls_f16x3": int(n16), "talkers_f32": len(p32), "talkers_f16x3": len(p16), "flips": fl})
-    rec = {"what": "hard-decision differences of the complete search, f16x3 vs exact f32 MFMA, same seeded FULL weights, "
+                     f"spot_calls_{mode}": int(n16), "talkers_f32": len(p32), f"talkers_{mode}": len(p16), "flips": fl})
+    rec = {"what": f"hard-decision differences of the complete search, {mode} vs exact f32 MFMA, same seeded FULL weights, "
                    "T=48000", "scenes": len(rows), "coarse_candidates": int(n_coarse), "fine_candidates": int(n_fine),
            "flips_total": tot,
            "flip_rate_per_candidate": (tot["coarse"] + tot["fine_accept"] + tot["fine_membership"]) / max(1, n_coarse + n_fine),
            "worst_position_difference_cm": worst_cm, "per_scene": rows}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "flip_rate_f16x3.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", out_name), "w") as f:
         json.dump(rec, f, indent=1)
-    _log(f"flip rate: {rec['scenes']} scenes, {n_coarse} coarse + {n_fine} fine candidates, flips {tot}, "
+    _log(f"flip rate {mode}: {rec['scenes']} scenes, {n_coarse} coarse + {n_fine} fine candidates, flips {tot}, "
          f"worst position difference {worst_cm:.4f} cm")
+    return rec
+
+
+def test_f16x3_flip_rate_full_size(full_weights):
+    rec = _flip_rate(full_weights, "f16x3", list(range(1001, 1009)) + list(range(1010, 1018)), "flip_rate_f16x3.json")
+    tot = rec["flips_total"]
     assert tot["final"] == 0 and tot["coarse"] == 0
     assert rec["flip_rate_per_candidate"] <= 1e-3
-    assert worst_cm <= 2.0
+    assert rec["worst_position_difference_cm"] <= 2.0
+
+
+def test_f16_single_pass_flip_rate(full_weights):
+    """The optional single-pass f16 mode (one MFMA per product, ~47 dB from f32 on the waveforms, 1.5x the f16x3
+    throughput): how many hard decisions of the search it changes on six full-size scenes.  It is NOT the
+    headline arithmetic and, unlike f16x3 (0 flips), it does move decisions: with the seeded RANDOM weights the
+    search sits on its thresholds (14-27 noise-like "talkers" per scene) and about 2 % of the candidates change
+    cluster, so the final cluster lists differ.  The record is what a user of the mode needs to know; the bar here
+    is only that it stays at that level (< 5 % of the candidates)."""
+    rec = _flip_rate(full_weights, "f16", [1001, 1002, 1003, 1010, 1011, 1012], "flip_rate_f16_single_pass.json")
+    assert rec["flip_rate_per_candidate"] <= 5e-2
 
 
 # ------------------------------------------------------------------------------ real multi-GPU

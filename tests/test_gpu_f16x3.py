@@ -147,6 +147,35 @@ def test_groupnorm_glu_on_load_is_bit_identical(T):
                      **dict(kw, pad=21))
 
 
+def test_single_pass_f16_mode_vs_reference_golden(golden):
+    """precision="f16": one MFMA per product on round-to-nearest fp16 halves (the reference's own half-precision
+    switch, `use_fp16`, is bf16 autocast and hard-wired off).  An OPTIONAL mode, never the headline: against the
+    reference's outputs the FULL network stays above 40 dB (47 measured; north-star tolerance 0.1 dB SI-SDR needs
+    ~35), per-layer error 2e-3 instead of 2e-5."""
+    from acousticswarms_speech_amd import ops
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.scenes import make_scene
+    g = golden("g4b_shift_and_sep_full")
+    m = _model(FULL, 5, batch=4)
+    m.set_precision("f16")
+    mix = torch.from_numpy(make_scene(2, 3, 7, 6000).mix)
+    y = m.shift_and_sep(mix, list(g["offsets"]), Strict=1)
+    per = [snr_db(y[i], g["y_strict1"][i]) for i in range(y.shape[0])]
+    _log(f"single-pass f16 shift_and_sep: per-candidate SNR vs reference {np.round(per, 1)}")
+    assert min(per) > 40.0
+    C, T, K = 128, 520, 7
+    x = _rand(2, T, C, seed=90).cuda()
+    w = _rand(C, C, K, seed=91, scale=1 / math.sqrt(C * K))
+    b, lg, lb = _rand(C, seed=92, scale=0.1).cuda(), (1 + 0.1 * _rand(C, seed=93)).cuda(), (0.1 * _rand(C, seed=94)).cuda()
+    Wt = ops.pack_conv_weight(w).cuda()
+    kw = dict(taps=K, dil=7, pad=21, bias=b, relu=True, resid=x, ln=(lg, lb))
+    want, _ = ops.convgemm(x, Wt, T, C, C, precision="f32", **kw)
+    got, _ = ops.convgemm(x, Wt, T, C, C, precision="f16", **kw)
+    rel = _rel(got.cpu(), want.cpu())
+    _log(f"single-pass f16 residual layer rel={rel:.2e}")
+    assert rel < 2e-3
+
+
 def test_fused_mask_path_matches_three_gemm_path(golden):
     """f16x3 runs the mask path as one launch by default (asw_mask_path_f16x3: no latent in memory); the
     three-GEMM path stays selectable.  Both against the reference's own output (g4b) and against each
