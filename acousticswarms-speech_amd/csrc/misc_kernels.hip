@@ -290,7 +290,7 @@ __global__ __launch_bounds__(1024) void energy_kernel(const float* __restrict__ 
 // float32 residual up to > 100 dB; the residual is clamped at 0 before MIN_ERR is added.
 // A workgroup owns a 16 x 16 block of pairs and streams T in 64-sample chunks through LDS: every
 // sample of the 32 rows is fetched once per block instead of once per pair (n = 301 waveforms of the
-// bench scene: 6.2 -> 0.3 ms).
+// bench scene: 6.2 -> 1.6 ms).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double sisdr_from_products(double ee, double ss, double es) {
   const double sss = es * es / ss;
@@ -337,6 +337,43 @@ __global__ __launch_bounds__(256) void pair_sisdr_kernel(const float* __restrict
   }
   const int i = i0 + ty, j = j0 + tx;
   if (i < n && j < n) out[(long)i * n + j] = sisdr_from_products(ee, ss, es);
+}
+
+// The same for a FEW waveforms (the per-coarse-patch calls of the fine stage: n ~ 12-38): 16 x 16-pair tiles
+// would leave a handful of workgroups streaming T one chunk after the other (measured 2.0 ms per call), so
+// here a workgroup owns 2 x 2 pairs and its 256 threads split T; the partial products meet in LDS.
+__global__ __launch_bounds__(256) void pair_sisdr_small_kernel(const float* __restrict__ y, int n, int T,
+                                                               double* __restrict__ out) {
+  __shared__ double red[4][8];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i0 = blockIdx.x * 2, j0 = blockIdx.y * 2;
+  const int i1 = i0 + 1 < n ? i0 + 1 : i0, j1 = j0 + 1 < n ? j0 + 1 : j0;      // a ragged edge repeats its row
+  const float* e0 = y + (long)i0 * T;
+  const float* e1 = y + (long)i1 * T;
+  const float* s0 = y + (long)j0 * T;
+  const float* s1 = y + (long)j1 * T;
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // ee0 ee1 ss0 ss1 e0s0 e0s1 e1s0 e1s1
+  for (int t = tid; t < T; t += 256) {
+    const double x0 = (double)e0[t], x1 = (double)e1[t], z0 = (double)s0[t], z1 = (double)s1[t];
+    a[0] += x0 * x0; a[1] += x1 * x1; a[2] += z0 * z0; a[3] += z1 * z1;
+    a[4] += x0 * z0; a[5] += x0 * z1; a[6] += x1 * z0; a[7] += x1 * z1;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = wave_sum_d(a[k]);
+    if (lane == 0) red[wid][k] = a[k];
+  }
+  __syncthreads();
+  if (tid < 4) {
+    const int di = tid >> 1, dj = tid & 1;
+    const int i = i0 + di, j = j0 + dj;
+    if (i < n && j < n) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+      out[(long)i * n + j] = sisdr_from_products(v[di], v[2 + dj], v[4 + di * 2 + dj]);
+    }
+  }
 }
 
 // Segment-wise SI-SDR (split_wise_sisdr, sep/helpers/eval_utils.py:73-82; call site
@@ -575,8 +612,12 @@ extern "C" int asw_segment_sisdr(const float* y, int n, int T, const int32_t* se
 extern "C" int asw_pair_sisdr(const float* y, int n, int T, double* out, void* stream) {
   ASW_CHECK_ARG(y && out, "pair_sisdr: null pointer");
   ASW_CHECK_ARG(n > 0 && n <= 65535 && T > 0, "pair_sisdr: bad shape");
-  hipLaunchKernelGGL(pair_sisdr_kernel, dim3(asw::cdiv(n, 16), asw::cdiv(n, 16)), dim3(256), 0, asw::as_stream(stream), y, n, T,
-                     out);
+  if (n <= 64)
+    hipLaunchKernelGGL(pair_sisdr_small_kernel, dim3(asw::cdiv(n, 2), asw::cdiv(n, 2)), dim3(256), 0, asw::as_stream(stream),
+                       y, n, T, out);
+  else
+    hipLaunchKernelGGL(pair_sisdr_kernel, dim3(asw::cdiv(n, 16), asw::cdiv(n, 16)), dim3(256), 0, asw::as_stream(stream), y, n, T,
+                       out);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }
