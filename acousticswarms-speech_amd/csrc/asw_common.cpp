@@ -24,7 +24,7 @@ int SmemAttr::ensure(const void* kern, size_t want) {
 }  // namespace asw
 
 extern "C" const char* asw_last_error(void) { return asw::err_buf(); }
-extern "C" int asw_abi_version(void) { return 2; }   // 2: + joint separation network (asw_sep_*)
+extern "C" int asw_abi_version(void) { return 3; }   // 2: + joint separation network (asw_sep_*); 3: + asw_resstack64_f16x3
 
 // ---- launch profiler -----------------------------------------------------------------
 #include <map>
@@ -32,7 +32,7 @@ extern "C" int asw_abi_version(void) { return 2; }   // 2: + joint separation ne
 #include <vector>
 namespace asw {
 namespace {
-struct Rec { std::string name; double work; hipEvent_t e0, e1; };
+struct Rec { std::string name; double work, bytes; hipEvent_t e0, e1; };
 std::mutex g_mu;
 bool g_on = false;
 bool g_detail = false;
@@ -52,10 +52,10 @@ std::string prof_name(const char* base, int bm, int bn, int bk, bool ln, bool st
   return b;
 }
 bool prof_detail() { return g_detail; }
-ProfScope::ProfScope(hipStream_t s, const std::string& name, double work) : slot(-1), stream(s) {
+ProfScope::ProfScope(hipStream_t s, const std::string& name, double work, double bytes) : slot(-1), stream(s) {
   if (!g_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  Rec r{name, work, take_event(), take_event()};
+  Rec r{name, work, bytes, take_event(), take_event()};
   (void)hipEventRecord(r.e0, s);
   g_recs.push_back(r);
   slot = (int)g_recs.size() - 1;
@@ -79,22 +79,22 @@ extern "C" int asw_profile_enable(int on) {
 extern "C" int asw_profile_report(char* buf, size_t cap) {
   if (!buf || cap < 64) return asw::set_error(ASW_ERR_ARG, "profile_report: buffer too small");
   std::lock_guard<std::mutex> lk(asw::g_mu);
-  struct Agg { long n = 0; double ms = 0, work = 0; };
+  struct Agg { long n = 0; double ms = 0, work = 0, bytes = 0; };
   std::map<std::string, Agg> agg;
   for (auto& r : asw::g_recs) {
     if (hipEventSynchronize(r.e1) != hipSuccess) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
     Agg& a = agg[r.name];
-    a.n += 1; a.ms += ms; a.work += r.work;
+    a.n += 1; a.ms += ms; a.work += r.work; a.bytes += r.bytes;
   }
   size_t off = 0;
   off += snprintf(buf + off, cap - off, "{");
   bool first = true;
   for (auto& kv : agg) {
-    if (off + 224 >= cap) break;
-    off += snprintf(buf + off, cap - off, "%s\"%s\":{\"launches\":%ld,\"ms\":%.6f,\"work\":%.6e}", first ? "" : ",",
-                    kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.work);
+    if (off + 256 >= cap) break;
+    off += snprintf(buf + off, cap - off, "%s\"%s\":{\"launches\":%ld,\"ms\":%.6f,\"work\":%.6e,\"bytes\":%.6e}", first ? "" : ",",
+                    kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.work, kv.second.bytes);
     first = false;
   }
   snprintf(buf + off, cap - off, "}");

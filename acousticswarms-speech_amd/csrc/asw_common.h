@@ -69,8 +69,10 @@ __device__ __forceinline__ float gn_glu_value(float a, float g, float m0, float 
 namespace asw {
 std::string prof_name(const char* base, int bm, int bn, int bk, bool ln, bool stats);
 bool prof_detail();
+// `work` = algorithmic FLOPs of the launch (GEMM-class kernels), `bytes` = algorithmic HBM bytes (the
+// memory-bound passes); either may be 0.
 struct ProfScope {
-  ProfScope(hipStream_t s, const std::string& name, double work);
+  ProfScope(hipStream_t s, const std::string& name, double work, double bytes = 0.0);
   ~ProfScope();
   int slot;
   hipStream_t stream;

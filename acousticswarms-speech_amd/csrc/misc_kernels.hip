@@ -226,48 +226,135 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restric
 // ---------------------------------------------------------------------------
 // Candidate energies (sep/helpers/local_utils_3d.py:13-17,349-354; Mic_Array.py:290-295):
 // x = y - mean(y); power = sum x^2; power2 = max_i sqrt(|mean(x^2[i:i+W])|) with zeros
-// past the end.  One workgroup per candidate; the prefix sum of x^2 goes through a
-// global scratch row (double) so window sums are c[min(i+W,T)] - c[i].
+// past the end, i.e. window sums c[min(i+W,T)] - c[i] of the prefix sum c of x^2 (double).
+//
+// One workgroup of 16 waves per candidate, every read coalesced (VEC consecutive samples per lane,
+// 64 * VEC per wave instruction), no prefix array in memory:
+//   1. mean (double sum, rounded to float32 like np.mean of a float32 row);
+//   2. the sum of x^2 of every 64*VEC-sample block -> LDS, exclusive scan by wave 0: P[j] = c[j * 64 * VEC];
+//   3. every wave walks a contiguous run of blocks with TWO cursors, one over x^2[i] and one over
+//      x^2[i + W]: in-lane prefix + a wave scan (shuffles) per block give c[i] and c[i + W] for the
+//      lane's samples, the running carries start from P[] (+ the partial block in front of i0 + W).
+// Bytes: the row is read four times (L2 hits after the first); round 2's version wrote and re-read a
+// (T+1)-double prefix row per candidate with per-thread contiguous (uncoalesced) chunks: 0.44 ms per
+// 256 candidates at T = 48 000.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void energy_kernel(const float* __restrict__ y, int T, int window,
-                                                      double* __restrict__ scratch, double* __restrict__ out) {
+__device__ __forceinline__ double wave_incl_scan_d(double v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double u = __shfl_up(v, o, 64);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
+constexpr int ENERGY_MAX_BLOCKS = 4096;
+
+template <int VEC>
+__global__ __launch_bounds__(1024) void energy_kernel(const float* __restrict__ y, int T, int window, double* __restrict__ out) {
+  constexpr int BLK = 64 * VEC;
   __shared__ double red[16];
-  __shared__ double scan[1024];
+  __shared__ double P[ENERGY_MAX_BLOCKS + 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* yb = y + (long)b * T;
-  double* c = scratch + (long)b * (T + 1);
+  const int nblk = (T + BLK - 1) / BLK;
+  // VEC samples of block j owned by this lane, zeros past the end of the row
+  auto load = [&](long i0, float (&v)[VEC]) {
+    if (VEC == 4 && i0 + 3 < T) {
+      const float4 f = *reinterpret_cast<const float4*>(yb + i0);
+      v[0] = f.x; v[1 % VEC] = f.y; v[2 % VEC] = f.z; v[3 % VEC] = f.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = i0 + e < T ? yb[i0 + e] : 0.f;
+    }
+  };
+  // ---- 1. mean
   double acc = 0.0;
-  for (int i = tid; i < T; i += 1024) acc += (double)yb[i];
+  for (int j = wid; j < nblk; j += 16) {
+    float v[VEC];
+    load((long)j * BLK + lane * VEC, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc += (double)v[e];
+  }
   acc = wave_sum_d(acc);
   if (lane == 0) red[wid] = acc;
   __syncthreads();
   double tot = 0.0;
   for (int i = 0; i < 16; ++i) tot += red[i];
   const float mu = (float)(tot / (double)T);     // np.mean of a float32 row is float32
-  // contiguous chunk per thread
-  const int chunk = (T + 1023) / 1024;
-  const int s0 = tid * chunk, s1 = s0 + chunk < T ? s0 + chunk : T;
-  double part = 0.0;
-  for (int i = s0; i < s1; ++i) { const float x = yb[i] - mu; part += (double)(x * x); }
-  scan[tid] = part;
-  __syncthreads();
-  // inclusive Hillis-Steele scan over 1024 partials
-  for (int o = 1; o < 1024; o <<= 1) {
-    const double v = tid >= o ? scan[tid - o] : 0.0;
-    __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
+  // squared, mean-removed samples of the lane (0 past the end)
+  auto squares = [&](long i0, float (&q)[VEC]) {
+    float v[VEC];
+    load(i0, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { const float x = v[e] - mu; q[e] = i0 + e < T ? x * x : 0.f; }
+  };
+  // ---- 2. block sums and their exclusive scan
+  for (int j = wid; j < nblk; j += 16) {
+    float q[VEC];
+    squares((long)j * BLK + lane * VEC, q);
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s += (double)q[e];
+    s = wave_sum_d(s);
+    if (lane == 0) P[j + 1] = s;
   }
-  double run = tid == 0 ? 0.0 : scan[tid - 1];
-  const double total = scan[1023];
-  if (tid == 0) c[0] = 0.0;
-  for (int i = s0; i < s1; ++i) { const float x = yb[i] - mu; run += (double)(x * x); c[i + 1] = run; }
-  __syncthreads();                               // same-workgroup global visibility
+  __syncthreads();
+  if (wid == 0) {
+    double carry = 0.0;
+    if (lane == 0) P[0] = 0.0;
+    for (int j0 = 0; j0 < nblk; j0 += 64) {
+      const double v = j0 + lane < nblk ? P[j0 + lane + 1] : 0.0;
+      const double inc = wave_incl_scan_d(v, lane) + carry;
+      if (j0 + lane < nblk) P[j0 + lane + 1] = inc;
+      carry = __shfl(inc, 63, 64);
+    }
+  }
+  __syncthreads();
+  const double total = P[nblk];
+  // ---- 3. windowed maximum: blocks [jb, je) of this wave
+  const int per = (nblk + 15) / 16;
+  const int jb = wid * per, je = jb + per < nblk ? jb + per : nblk;
   double best = 0.0;
-  for (int i = tid; i < T; i += 1024) {
-    const int hi = i + window < T ? i + window : T;
-    const double w = fabs((c[hi] - c[i]) / (double)window);
-    best = w > best ? w : best;
+  if (jb < je) {
+    double carryA = P[jb];
+    // c[min(jb*BLK + W, T)]: whole blocks from P, the partial block in front of it summed here
+    double carryB;
+    {
+      const long s = (long)jb * BLK + window;
+      if (s >= T) carryB = total;
+      else {
+        const int js = (int)(s / BLK);
+        float q[VEC];
+        squares((long)js * BLK + lane * VEC, q);
+        double part = 0.0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) part += ((long)js * BLK + lane * VEC + e < s) ? (double)q[e] : 0.0;
+        carryB = P[js] + wave_sum_d(part);
+      }
+    }
+    for (int j = jb; j < je; ++j) {
+      const long i0 = (long)j * BLK + lane * VEC;
+      float qa[VEC], qb[VEC];
+      squares(i0, qa);
+      squares(i0 + window, qb);
+      double ta = 0.0, tb = 0.0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { ta += (double)qa[e]; tb += (double)qb[e]; }
+      const double ia = wave_incl_scan_d(ta, lane), ib = wave_incl_scan_d(tb, lane);
+      double ca = carryA + (ia - ta), cb = carryB + (ib - tb);       // c[i0], c[i0 + W]
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (i0 + e < T) {
+          const double w = fabs((cb - ca) / (double)window);
+          best = w > best ? w : best;
+        }
+        ca += (double)qa[e];
+        cb += (double)qb[e];
+      }
+      carryA += __shfl(ia, 63, 64);
+      carryB += __shfl(ib, 63, 64);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const double v = __shfl_xor(best, o, 64); best = v > best ? v : best; }
@@ -506,6 +593,7 @@ extern "C" int asw_add_layernorm(const float* x, const float* resid, const float
   if (rows == 0) return ASW_OK;
   hipStream_t s = asw::as_stream(stream);
   dim3 grid(asw::cdiv(rows, 4));
+  asw::ProfScope prof(s, "add_layernorm", 0.0, (double)rows * N * 12);     // x, residual read; result written
   switch (N / 256) {
 #define ASW_ALN(NV) case NV: hipLaunchKernelGGL(add_layernorm_kernel<NV>, grid, dim3(256), 0, s, x, resid, gamma, beta, rows, eps, out); break;
     ASW_ALN(1) ASW_ALN(2) ASW_ALN(3) ASW_ALN(4) ASW_ALN(5) ASW_ALN(6) ASW_ALN(7) ASW_ALN(8)
@@ -529,6 +617,8 @@ extern "C" int asw_gn_glu(const float* raw, const float* stats, int n_partials, 
   ASW_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && n_partials > 0, "gn_glu: bad shape");
   const int items = 256 * 8;
   dim3 grid(asw::cdiv((long)T * (C / 4), items), B);
+  // algorithmic bytes: the 2C-channel pre-GLU tensor read, the C-channel result written
+  asw::ProfScope prof(asw::as_stream(stream), "gn_glu", 0.0, (double)B * T * C * 12);
   hipLaunchKernelGGL(gn_glu_kernel, grid, dim3(256), 0, asw::as_stream(stream), raw, stats, n_partials, gamma, beta,
                      T, C, eps, out, items);
   ASW_LAUNCH_CHECK();
@@ -584,6 +674,8 @@ extern "C" int asw_overlap_add_parts(const float* D, int nparts, int B, int F, i
   ASW_CHECK_ARG((mean == nullptr) == (std == nullptr), "overlap_add: mean/std must both be given or both NULL");
   ASW_CHECK_ARG(B <= 65535, "overlap_add: batch too large");
   dim3 grid(asw::cdiv(t, 256), B);
+  // algorithmic bytes: the tap tensors read, the waveform written
+  asw::ProfScope prof(asw::as_stream(stream), "overlap_add", 0.0, (double)nparts * B * F * taps * 4 + (double)B * t * 4);
   hipLaunchKernelGGL(overlap_add_kernel, grid, dim3(256), 0, asw::as_stream(stream), D, nparts, (long)B * F * ldd, F, ldd,
                      taps, hop, t, lead, bias, mean, std, out);
   ASW_LAUNCH_CHECK();
@@ -591,10 +683,20 @@ extern "C" int asw_overlap_add_parts(const float* D, int nparts, int B, int F, i
 }
 
 extern "C" int asw_energies(const float* y, int B, int T, int window, double* scratch, double* out, void* stream) {
-  ASW_CHECK_ARG(y && scratch && out, "energies: null pointer");
+  ASW_CHECK_ARG(y && out, "energies: null pointer");
   ASW_CHECK_ARG(T > 0 && window > 0, "energies: bad shape");
   if (B == 0) return ASW_OK;
-  hipLaunchKernelGGL(energy_kernel, dim3(B), dim3(1024), 0, asw::as_stream(stream), y, T, window, scratch, out);
+  (void)scratch;                                       // kept in the ABI; the prefix sums no longer go through memory
+  hipStream_t s = asw::as_stream(stream);
+  asw::ProfScope prof(s, "energy", 0.0, (double)B * T * 4);
+  // four samples per lane when every row is 16-byte aligned, one otherwise
+  if (T % 4 == 0 && window % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+    ASW_CHECK_ARG(T <= ENERGY_MAX_BLOCKS * 256, "energies: T=%d too long", T);
+    hipLaunchKernelGGL(energy_kernel<4>, dim3(B), dim3(1024), 0, s, y, T, window, out);
+  } else {
+    ASW_CHECK_ARG(T <= ENERGY_MAX_BLOCKS * 64, "energies: T=%d too long for unaligned rows", T);
+    hipLaunchKernelGGL(energy_kernel<1>, dim3(B), dim3(1024), 0, s, y, T, window, out);
+  }
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }

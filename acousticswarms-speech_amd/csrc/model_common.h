@@ -3,6 +3,7 @@
 // sep/training/SpeakerSeparation/network.py): device buffers, GEMM weights in both arithmetic
 // forms, the dilated-residual stack and the linear-layer launch helper.
 #pragma once
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -155,11 +156,54 @@ inline bool glu_on_load_ok(const std::vector<ResLayer>& res, int prec, int ch) {
   return prec >= 1 && ch == 64 && !res.empty() && res[0].dil == 1 && res[0].wt.fhi && res[0].wt.flo;
 }
 
+// 64-channel stacks in f16x3 arithmetic run through asw_resstack64_f16x3 (resstack.hip): consecutive layers whose
+// later dilations leave most of a 256-row tile (summed halo <= 64 rows per side) share ONE launch, the rest
+// (dilation 49) run as single layers of the same kernel.  ASW_NO_RESSTACK=1 keeps the per-layer kernels
+// of convgemm.hip (A/B measurements).
+inline bool resstack_ok(const std::vector<ResLayer>& res, int prec, int ch, int K) {
+  static const bool off = getenv("ASW_NO_RESSTACK") != nullptr;
+  if (off || prec < 1 || ch != 64 || K % 2 == 0 || K < 3 || K > 15) return false;
+  for (const ResLayer& r : res)
+    if (!r.wt.fhi || !r.wt.flo) return false;
+  return true;
+}
+
 inline int run_res(const std::vector<ResLayer>& res, int prec, int B, int T, int ch, int K, float* x, float* p, float* q,
             float** final_out, hipStream_t s, const GluSrc* glu = nullptr) {
   // ping-pong: layer 0 reads x (kept intact), later layers alternate p/q
   const float* in = glu ? glu->raw : x;
   float* outb = p;
+  if (resstack_ok(res, prec, ch, K)) {
+    static const bool nofuse = getenv("ASW_RESSTACK_NOFUSE") != nullptr;
+    size_t j = 0;
+    while (j < res.size()) {
+      size_t n = 1;
+      int halo = 0;
+      while (!nofuse && j + n < res.size() && n < 3) {
+        const int pad = res[j + n].dil * (K - 1) / 2;
+        if (halo + pad > 64) break;
+        halo += pad;
+        ++n;
+      }
+      asw_resstack_args a = {};
+      a.x = (glu && j == 0) ? nullptr : in;
+      a.out = outb;
+      a.B = B; a.T = T; a.C = ch; a.taps = K; a.n_layers = (int)n; a.precision = prec; a.ln_eps = 1e-5f;
+      for (size_t i = 0; i < n; ++i) {
+        const ResLayer& r = res[j + i];
+        a.layer[i].Wf_hi = r.wt.fhi; a.layer[i].Wf_lo = r.wt.flo; a.layer[i].w_shift = r.wt.shift;
+        a.layer[i].bias = r.bias.p; a.layer[i].ln_gamma = r.g.p; a.layer[i].ln_beta = r.b.p; a.layer[i].dil = r.dil;
+      }
+      if (glu && j == 0) { a.glu_raw = glu->raw; a.glu_mr = glu->mr; a.glu_gamma = glu->gamma; a.glu_beta = glu->beta; }
+      int rc = asw_resstack64_f16x3(&a, s);
+      if (rc) return rc;
+      in = outb;
+      outb = (outb == p) ? q : p;
+      j += n;
+    }
+    *final_out = const_cast<float*>(in);
+    return ASW_OK;
+  }
   for (size_t j = 0; j < res.size(); ++j) {
     asw_convgemm_args a = {};
     a.A = in; res[j].wt.bind(a, prec); a.bias = res[j].bias.p; a.resid = in;

@@ -149,6 +149,8 @@ extern "C" int asw_shift_stats(const float* mix, int M, int T, const int32_t* of
   ASW_CHECK_ARG(mix && offsets && mean && std, "shift_stats: null pointer");
   ASW_CHECK_ARG(M >= 1 && M <= MAX_MICS && T >= 2, "shift_stats: M=%d T=%d unsupported", M, T);
   if (N == 0) return ASW_OK;
+  // algorithmic bytes: the M x T mixture once (every candidate re-reads it from L2) + the statistics
+  asw::ProfScope prof(asw::as_stream(stream), "shift_stats", 0.0, (double)M * T * 4 + (double)N * 8);
   hipLaunchKernelGGL(shift_stats_kernel, dim3(N), dim3(1024), 0, asw::as_stream(stream), mix, M, T, offsets,
                      circular, mean, std);
   ASW_LAUNCH_CHECK();
@@ -166,6 +168,8 @@ extern "C" int asw_shift_norm_preproc(const float* mix, int M, int T, int T_pad,
   if (N == 0) return ASW_OK;
   const int rows = 64;
   dim3 grid(asw::cdiv(T_pad, rows), N);
+  // algorithmic bytes: the mixture once + the [N][T_pad][C] activation and the reference channel written
+  asw::ProfScope prof(asw::as_stream(stream), "preproc", 0.0, (double)M * T * 4 + (double)N * T_pad * (C + 1) * 4);
   hipLaunchKernelGGL(preproc_kernel<true>, grid, dim3(256), 0, asw::as_stream(stream), mix, M, T, T_pad, offsets,
                      circular, mean, std, w, b, C, x0, refn, refn_stride, rows);
   ASW_LAUNCH_CHECK();

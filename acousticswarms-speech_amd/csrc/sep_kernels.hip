@@ -499,10 +499,10 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float*
 // One wave per (n, t, head): the S x hd blocks of q, k, v are staged once into LDS (rows padded
 // to hd+1 floats so the per-lane row walks are conflict free); lane s2 computes the scores
 // (s1, s2) for every s1 with an in-lane dot product, the softmax runs across lanes, and for the
-// output lane = head dimension.  S <= 64, hd <= 64.
+// output lane = head dimension.  S <= 64, hd <= 64.  IA_WAVES waves (units) per workgroup: 4 while their
+// regions fit the CU's LDS (S <= 38 at hd = 64), else 2 (any S <= 64: 2 x 66 KB at S = 64, hd = 64) or 1.
 // ---------------------------------------------------------------------------------------
-constexpr int IA_WAVES = 4;
-
+template <int IA_WAVES>
 __global__ __launch_bounds__(64 * IA_WAVES) void inter_attention_kernel(const float* __restrict__ qkv, int NB, int S, int L,
                                                                         int d, int nhead, float* __restrict__ ctx) {
   extern __shared__ __align__(16) float smem[];
@@ -659,12 +659,21 @@ extern "C" int asw_inter_attention(const float* qkv, int NB, int S, int L, int d
   ASW_CHECK_ARG(NB > 0 && S > 0 && S <= 64 && L > 0 && nhead > 0 && d % nhead == 0 && d / nhead <= 64,
                 "inter_attention: bad shape (S <= 64, head_dim <= 64)");
   const int hd = d / nhead;
-  const size_t smem = sizeof(float) * (size_t)IA_WAVES * (3 * (size_t)S * (hd + 1) + (size_t)S * 64);
-  static asw::SmemAttr attr;                                   // per device
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(inter_attention_kernel), smem)) return rc;
-  dim3 grid(asw::cdiv((long)NB * L * nhead, IA_WAVES));
-  hipLaunchKernelGGL(inter_attention_kernel, grid, dim3(64 * IA_WAVES), smem, asw::as_stream(stream), qkv, NB, S, L, d, nhead,
-                     ctx);
+  const size_t per_wave = sizeof(float) * (3 * (size_t)S * (hd + 1) + (size_t)S * 64);
+  const size_t lds_max = 160 * 1024;
+  const int waves = 4 * per_wave <= lds_max ? 4 : 2 * per_wave <= lds_max ? 2 : 1;
+  ASW_CHECK_ARG(per_wave <= lds_max, "inter_attention: S=%d x head_dim %d needs %zu bytes of LDS per wave", S, hd, per_wave);
+  const size_t smem = per_wave * waves;
+  const void* kern = waves == 4 ? reinterpret_cast<const void*>(inter_attention_kernel<4>)
+                   : waves == 2 ? reinterpret_cast<const void*>(inter_attention_kernel<2>)
+                                : reinterpret_cast<const void*>(inter_attention_kernel<1>);
+  static asw::SmemAttr attr[3];                                // per device and instantiation
+  if (int rc = attr[waves == 4 ? 0 : waves == 2 ? 1 : 2].ensure(kern, smem)) return rc;
+  dim3 grid(asw::cdiv((long)NB * L * nhead, waves));
+  hipStream_t st = asw::as_stream(stream);
+  if (waves == 4) hipLaunchKernelGGL(inter_attention_kernel<4>, grid, dim3(256), smem, st, qkv, NB, S, L, d, nhead, ctx);
+  else if (waves == 2) hipLaunchKernelGGL(inter_attention_kernel<2>, grid, dim3(128), smem, st, qkv, NB, S, L, d, nhead, ctx);
+  else hipLaunchKernelGGL(inter_attention_kernel<1>, grid, dim3(64), smem, st, qkv, NB, S, L, d, nhead, ctx);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }

@@ -705,6 +705,12 @@ extern "C" int asw_sep_forward(asw_sep* m, const float* mix_norm, int B, int S, 
   return ASW_OK;
 }
 
+extern "C" int asw_sep_get_config(const asw_sep* m, asw_sep_config* out) {
+  ASW_CHECK_ARG(m && out, "sep_get_config: null pointer");
+  *out = m->cfg;
+  return ASW_OK;
+}
+
 extern "C" int asw_sep_get_tap(asw_sep* m, const char* name, float* dst, size_t capacity, size_t* numel, void* stream) {
   ASW_CHECK_ARG(m && name && numel, "sep_get_tap: null pointer");
   auto it = m->taps.find(name);

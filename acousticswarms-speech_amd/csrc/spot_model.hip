@@ -601,27 +601,37 @@ extern "C" int asw_spot_shift_and_sep(asw_spot* m, const float* mix, int M, int 
     ASW_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
   }
   const int C = m->cfg.channels, pad_l = m->cfg.encoder_kernel_size / 2;
-  int k = 0;
-  for (int i0 = 0; i0 < N; i0 += Bmax, ++k) {
-    const int B = N - i0 < Bmax ? N - i0 : Bmax;
-    Plan& p = pl[k % lanes];
-    hipStream_t q = st[k % lanes];
-    p.B = B;
-    const int32_t* off = offsets + (size_t)i0 * (M - 1);
-    ASW_HIP(hipMemsetAsync(p.refn, 0, (size_t)B * p.RL * sizeof(float), q));
-    if ((rc = asw_shift_stats(mix, M, T, off, B, circular, p.mean, p.stdv, q))) return rc;
-    if ((rc = asw_shift_norm_preproc(mix, M, T, p.Tp, off, B, circular, p.mean, p.stdv, m->pre_w.p, m->pre_b.p, C,
-                                     p.X[0], p.refn + pad_l, p.RL, q)))
-      return rc;
-    float* y = out_wave ? out_wave + (size_t)i0 * T : p.ywave;
-    if ((rc = run_network(m, p, gs, p.mean, p.stdv, y, q))) return rc;
-    if (out_energy && (rc = asw_energies(y, B, T, energy_window, p.escr, out_energy + (size_t)i0 * 2, q))) return rc;
+  // The caller's stream continues after BOTH lanes on every exit path: when a launch fails half way the side
+  // lane may still be writing out_wave / out_energy (the caller's buffers), so the join is not skipped -- and if
+  // the join itself cannot be queued the side lane is drained before the status is returned.
+  auto batches = [&]() -> int {
+    int k = 0;
+    for (int i0 = 0; i0 < N; i0 += Bmax, ++k) {
+      const int B = N - i0 < Bmax ? N - i0 : Bmax;
+      Plan& p = pl[k % lanes];
+      hipStream_t q = st[k % lanes];
+      p.B = B;
+      const int32_t* off = offsets + (size_t)i0 * (M - 1);
+      ASW_HIP(hipMemsetAsync(p.refn, 0, (size_t)B * p.RL * sizeof(float), q));
+      int r;
+      if ((r = asw_shift_stats(mix, M, T, off, B, circular, p.mean, p.stdv, q))) return r;
+      if ((r = asw_shift_norm_preproc(mix, M, T, p.Tp, off, B, circular, p.mean, p.stdv, m->pre_w.p, m->pre_b.p, C,
+                                      p.X[0], p.refn + pad_l, p.RL, q)))
+        return r;
+      float* y = out_wave ? out_wave + (size_t)i0 * T : p.ywave;
+      if ((r = run_network(m, p, gs, p.mean, p.stdv, y, q))) return r;
+      if (out_energy && (r = asw_energies(y, B, T, energy_window, p.escr, out_energy + (size_t)i0 * 2, q))) return r;
+    }
+    return ASW_OK;
+  };
+  rc = batches();
+  if (lanes == 2) {
+    if (hipEventRecord(m->ev_join, m->side) != hipSuccess || hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess) {
+      (void)hipStreamSynchronize(m->side);
+      if (!rc) rc = asw::set_error(ASW_ERR_HIP, "shift_and_sep: joining the side lane failed");
+    }
   }
-  if (lanes == 2) {                                         // the caller's stream continues after both lanes
-    ASW_HIP(hipEventRecord(m->ev_join, m->side));
-    ASW_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
-  }
-  return ASW_OK;
+  return rc;
 }
 
 extern "C" int asw_spot_set_lanes(asw_spot* m, int lanes) {

@@ -144,6 +144,10 @@ extern "C" int asw_srp_map(const float* cc, int n_windows, int nbins, int P, con
   const int KS = 8, kps = asw::cdiv(nbins, KS);
   const float scale = 1.0f / ((float)nbins * (float)P);
   const size_t smem = (size_t)M * 256 * sizeof(double);
+  // the steered-response map: G x nbins x P sincos + complex MACs per window (VALU-bound); algorithmic bytes
+  // = cross spectra + delays read, map written
+  asw::ProfScope prof(s, "srp_map", 8.0 * (double)G * nbins * P * n_windows,
+                      (double)n_windows * nbins * P * 8 + (double)G * M * 8 + (double)G * 4);
   for (int w0 = 0; w0 < n_windows; w0 += MAP_W) {
     const int W = n_windows - w0 < MAP_W ? n_windows - w0 : MAP_W;
     hipLaunchKernelGGL(srp_partial_kernel, dim3(asw::cdiv(G, 256), KS), dim3(256), smem, s,

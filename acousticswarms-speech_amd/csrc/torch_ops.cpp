@@ -232,7 +232,14 @@ Tensor sep_forward(int64_t model, const Tensor& mix_norm, int64_t n_speakers, in
   const int B = checked_int(mix_norm.size(0), "B"), t = checked_int(mix_norm.size(2), "t");
   const int S = checked_int(n_speakers, "S"), M = checked_int(n_mics, "M");
   TORCH_CHECK(S >= 1 && mix_norm.size(1) == (int64_t)S * M, "mix must be [B, S*M, t]");
-  const int64_t R = S > max_speakers ? S : max_speakers;
+  // the library pads the rows of `out` to the HANDLE's max_speakers: the caller's view of the model must agree,
+  // or the copy would run past the tensor allocated here
+  asw_sep_config cfg;
+  check_status(asw_sep_get_config(reinterpret_cast<asw_sep*>(model), &cfg), "asw_sep_get_config");
+  TORCH_CHECK(cfg.n_mics == M, "sep_forward: n_mics=", M, " but the model was built for ", cfg.n_mics);
+  TORCH_CHECK(cfg.max_speakers == max_speakers, "sep_forward: max_speakers=", max_speakers, " but the model was built for ",
+              cfg.max_speakers);
+  const int64_t R = S > cfg.max_speakers ? S : cfg.max_speakers;
   Tensor out = at::empty({B, R, t}, mix_norm.options());
   if (B == 0) return out;
   Launch l(mix_norm);

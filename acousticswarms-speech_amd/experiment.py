@@ -43,6 +43,9 @@ def config_from_description(desc: dict):
     if "stride_list" in base:
         base["stride_list"] = tuple(int(v) for v in base["stride_list"])
     if "growth" in base:
+        # the reference widens by int(growth * channels); the device networks take whole-number factors only
+        if float(base["growth"]) != int(base["growth"]):
+            raise RuntimeError(f"description.json: growth={base['growth']} -- only whole-number channel growth is supported")
         base["growth"] = int(base["growth"])
     return kind, cls(**base)
 
@@ -52,9 +55,16 @@ def _safe_load(path):
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
-def load_model_from_exp(exp_dir: str, mode: str = "best", precision: str = "f32", **model_kwargs):
+def load_model_from_exp(exp_dir: str, mode: str = "best", precision: str = "f32", best_epoch=None,
+                        fallback_to_last: bool = False, **model_kwargs):
     """-> SpotModel / SepModel with the experiment's weights (not yet moved to a device).
-    mode: 'best' (argmin of state.pt's val_losses), 'last' (highest epoch), 'new' (no weights)."""
+    mode: 'best' (argmin of state.pt's val_losses), 'last' (highest epoch), 'new' (no weights).
+
+    The reference's state.pt also holds a pickled scheduler object (train.py:219-226), which the safe loader
+    (weights_only=True) refuses -- and nothing from a checkpoint file is ever unpickled here.  For such an
+    experiment 'best' needs the epoch from the caller (`best_epoch`, e.g. read off the training log) or an
+    explicit `fallback_to_last=True`; silently evaluating another checkpoint than the reference would is not
+    an option.  A missing state.pt falls back to 'last' with a warning, as the reference does (utils.py:186-190)."""
     with open(os.path.join(exp_dir, "description.json"), "rb") as f:
         desc = json.load(f)
     if "experiment_name" in desc:
@@ -71,16 +81,24 @@ def load_model_from_exp(exp_dir: str, mode: str = "best", precision: str = "f32"
         from .sep import SepModel
         model = SepModel(cfg, None, precision=precision, **model_kwargs)
     if mode == "best":
+        import pickle
         state_path = os.path.join(exp_dir, ckpt_dir, "state.pt")
-        best = None
-        if not os.path.exists(state_path):
+        best = None if best_epoch is None else int(best_epoch)
+        if best is not None:
+            pass
+        elif not os.path.exists(state_path):
             print("[WARNING] Could not find experiment state dict, using load mode 'last' instead")
         else:
             try:
-                best = int(np.argmin(np.asarray(_safe_load(state_path)["val_losses"], dtype=np.float64)))
-            except Exception as e:          # the safe loader refuses pickled objects: do not execute them
-                print(f"[WARNING] state.pt is not loadable without unpickling ({type(e).__name__}); "
-                      "using load mode 'last' instead")
+                state = _safe_load(state_path)
+            except pickle.UnpicklingError as e:  # pickled objects inside: refused, never executed
+                if not fallback_to_last:
+                    raise RuntimeError(
+                        f"{state_path} cannot be read without unpickling ({e}); pass best_epoch=<epoch> or "
+                        "fallback_to_last=True to choose the checkpoint explicitly") from e
+                print("[WARNING] state.pt is not loadable without unpickling; using load mode 'last' as requested")
+            else:
+                best = int(np.argmin(np.asarray(state["val_losses"], dtype=np.float64)))
         if best is None:
             mode = "last"
         else:

@@ -45,7 +45,7 @@ class JointModel(object):
         self.times = [0, 0, 0, 0, 0]
         self.previous_config = None
         self.Mic_processor = None
-        self._mix_dev = None
+        self._mix_dev = self._mix_src = None
 
     def setup(self, mic_positions, speaker_range, cached=False, cached_folder=None):
         """(Re)build the geometry tables unless the configuration is unchanged (:125-137).
@@ -76,6 +76,7 @@ class JointModel(object):
         audio = self.separate_by_localization(mix_data, patches)
         _sync()
         self.times[4] = time.time() - t0
+        self._mix_dev = self._mix_src = None              # the resident copy does not outlive the forward
         return patches, audio_loc, audio, SRP_drop, stage1_drop, spot_times
 
     __call__ = forward
@@ -97,10 +98,11 @@ class JointModel(object):
         # the resident copy (a host tensor would be copied again by every stage -- and a pageable
         # H2D right after the fine stage was measured at 29 ms for these 1.3 MB).  Any other
         # duck-typed model keeps receiving the caller's tensor.
-        self._mix_dev = None
+        self._mix_dev = self._mix_src = None
 
         def srp_stage(m):
             self._mix_dev = self._resident(m)
+            self._mix_src = m                             # the resident copy stands for THIS object only
             return mp.Apply_SRP_PHAT(m)
         patch_list, _ = self._timed(0, srp_stage, mix_data)
         if self._takes_resident(self.spot_model) and self._mix_dev is not None:
@@ -138,9 +140,12 @@ class JointModel(object):
     def separate_by_localization(self, mix_data, target_patches):
         if len(target_patches) == 0 or self.sep_model is None:
             return None
-        if self._takes_resident(self.sep_model) and getattr(self, "_mix_dev", None) is not None \
-                and tuple(self._mix_dev.shape) == tuple(mix_data.shape):
-            mix_data = self._mix_dev
+        # the resident copy uploaded by localize_by_separation() is reused only for the very object it was made
+        # from (or for itself): a different mixture of the same shape must not be swapped for the cached one
+        cached = getattr(self, "_mix_dev", None)
+        if self._takes_resident(self.sep_model) and cached is not None \
+                and (mix_data is getattr(self, "_mix_src", None) or mix_data is cached):
+            mix_data = cached
         return self.sep_model.infer(mix_data, [p[0] for p in target_patches])
 
     def to(self, device=None):

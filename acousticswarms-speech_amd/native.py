@@ -14,9 +14,9 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASW_LIB_PATH") or os.path.join(_HERE, "libasw_hip.so")   # env: A/B builds only
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["asw_common.cpp", "convgemm.hip", "prep_kernels.hip", "misc_kernels.hip", "attention_mfma.hip", "srp_kernels.hip",
+SOURCES = ["asw_common.cpp", "convgemm.hip", "resstack.hip", "prep_kernels.hip", "misc_kernels.hip", "attention_mfma.hip", "srp_kernels.hip",
            "search_host.cpp", "sep_kernels.hip", "spot_model.hip", "sep_model.hip"]
-HEADERS = ["asw_common.h", "model_common.h"]
+HEADERS = ["asw_common.h", "model_common.h", "mfma_util.h"]
 OPS_PATH = os.path.join(_HERE, "libasw_torch_ops.so")      # TORCH_LIBRARY(asw, ...) adapters over the C ABI
 OPS_SOURCE = "torch_ops.cpp"
 
@@ -132,6 +132,17 @@ class MaskPathArgs(Structure):
                 ("dec_lo", c_void_p), ("dec_shift", c_int32), ("dec_taps", c_int32), ("taps", c_void_p)]
 
 
+class ResLayerDesc(Structure):
+    _fields_ = [("Wf_hi", c_void_p), ("Wf_lo", c_void_p), ("bias", c_void_p), ("ln_gamma", c_void_p),
+                ("ln_beta", c_void_p), ("dil", c_int32), ("w_shift", c_int32)]
+
+
+class ResStackArgs(Structure):
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("B", c_int32), ("T", c_int32), ("C", c_int32), ("taps", c_int32),
+                ("n_layers", c_int32), ("precision", c_int32), ("ln_eps", c_float), ("layer", ResLayerDesc * 3),
+                ("glu_raw", c_void_p), ("glu_mr", c_void_p), ("glu_gamma", c_void_p), ("glu_beta", c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/asw_hip.h
 SIGNATURES = {
     "asw_last_error": (c_char_p, []),
@@ -159,6 +170,7 @@ SIGNATURES = {
     "asw_sep_set_precision": (c_int, [c_void_p, c_int]),
     "asw_sep_infer": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "asw_sep_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "asw_sep_get_config": (c_int, [c_void_p, POINTER(SepConfigC)]),
     "asw_sep_get_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]),
     "asw_joint_shift_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "asw_joint_shift_stats_scratch_doubles": (c_int, []),
@@ -177,6 +189,7 @@ SIGNATURES = {
                                 c_void_p, c_long, c_void_p]),
     "asw_convgemm_f32": (c_int, [POINTER(ConvGemmArgs), c_void_p]),
     "asw_mask_path_f16x3": (c_int, [POINTER(MaskPathArgs), c_void_p]),
+    "asw_resstack64_f16x3": (c_int, [POINTER(ResStackArgs), c_void_p]),
     "asw_convgemm_stats_tiles": (c_int, [c_int, c_int]),
     "asw_f16x3_overflow_count": (c_int, [c_int, POINTER(c_int32)]),
     "asw_gn_glu": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,

@@ -8,7 +8,7 @@ from ctypes import byref
 
 import torch
 
-from .native import ConvGemmArgs, MaskPathArgs, check, current_stream, lib, ptr
+from .native import ConvGemmArgs, MaskPathArgs, ResStackArgs, check, current_stream, lib, ptr
 
 
 def _f32(t):
@@ -67,6 +67,32 @@ def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, re
     check(lib().asw_convgemm_f32(byref(a), current_stream()))
     torch.cuda.current_stream().synchronize() if keep is not None else None
     return out, stats
+
+
+def resstack(x, layers, taps=7, precision="f16x3", eps=1e-5, glu=None, out=None):
+    """A stack of 1..3 64-channel residual layers in one launch (include/asw_hip.h:asw_resstack64_f16x3).
+    layers: [(Wt [64][taps*64], bias, gamma, beta, dil), ...]; x [B][T][64] or None with glu = (raw, mr, gamma, beta)."""
+    src = x if glu is None else glu[0]
+    B, T = src.shape[0], src.shape[1]
+    if out is None:
+        out = torch.empty((B, T, 64), dtype=torch.float32, device=src.device)
+    a = ResStackArgs()
+    a.x = _f32(x).data_ptr() if x is not None else None
+    a.out = out.data_ptr()
+    a.B, a.T, a.C, a.taps, a.n_layers = B, T, 64, taps, len(layers)
+    a.precision, a.ln_eps = (1 if precision == "f16x3" else 2), eps
+    keep = []
+    for i, (Wt, bias, gamma, beta, dil) in enumerate(layers):
+        fh, fl, sh = pack_fragments_f16(_f32(Wt), 64, taps * 64)
+        keep.append((fh, fl))
+        d = a.layer[i]
+        d.Wf_hi, d.Wf_lo, d.w_shift, d.dil = fh.data_ptr(), fl.data_ptr(), sh, dil
+        d.bias, d.ln_gamma, d.ln_beta = _f32(bias).data_ptr(), _f32(gamma).data_ptr(), _f32(beta).data_ptr()
+    if glu is not None:
+        a.glu_raw, a.glu_mr, a.glu_gamma, a.glu_beta = (_f32(t).data_ptr() for t in glu)
+    check(lib().asw_resstack64_f16x3(byref(a), current_stream()))
+    torch.cuda.current_stream().synchronize()
+    return out
 
 
 def pack_fragments_f16(Wt, N, K):

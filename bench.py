@@ -34,6 +34,7 @@ import torch  # noqa: E402
 # f16x3 mode every algorithmic product costs three f16 MFMAs, so the ceiling for ALGORITHMIC
 # flops is 2500 / 3.
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3.0}
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured for a float4 copy)
 # What the matrix pipe sustains on this chip with random (non-zero) fp16 operands and nothing else
 # running: 1.63 PFLOP/s of v_mfma_f32_32x32x16_f16 (2.2 with all-zero operands), i.e. the clock is
 # power-limited under dense MFMA load (tests/micro/cu_probe.hip, profiles/r1/cu_probe_random_operands.txt).
@@ -139,6 +140,27 @@ def e2e_latency(model, sep_model, scene, dev):
         for _ in range(3):
             out = jm.forward(mix)
             runs.append(list(jm.times))
+        # one more forward with the in-library launch timer on: the SRP map kernel (K10) against its rooflines
+        srp_rec = None
+        try:
+            from acousticswarms_speech_amd import native
+            L = native.lib()
+            L.asw_profile_enable(1)
+            jm.forward(mix)
+            torch.cuda.synchronize()
+            buf = ctypes.create_string_buffer(1 << 16)
+            native.check(L.asw_profile_report(buf, len(buf)))
+            L.asw_profile_enable(0)
+            pr = json.loads(buf.value.decode()).get("srp_map")
+            if pr:
+                srp_rec = {"ms": round(pr["ms"] / pr["launches"], 4),
+                           "achieved_gbs": round(pr["bytes"] / (pr["ms"] * 1e-3) / 1e9, 1),
+                           "frac_of_8tbs": round(pr["bytes"] / (pr["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                           "gop_per_s": round(pr["work"] / (pr["ms"] * 1e-3) / 1e9, 1),
+                           "note": "steered-response accumulation: one sincos + complex MAC per (grid point, bin, pair, "
+                                   "window), VALU-bound; its bytes (cross spectra + delays + map) are far from the HBM roof"}
+        except Exception as exc:                          # diagnostic only
+            srp_rec = {"error": f"{type(exc).__name__}: {exc}"}
     runs.sort(key=sum)
     times = runs[1]                                       # the median forward of three
     mp = jm.Mic_processor
@@ -147,7 +169,7 @@ def e2e_latency(model, sep_model, scene, dev):
     rec = {"unit": "ms", "stages": stages, "protocol": "3 warm-up forwards, median (by total) of 3 measured forwards",
            "totals_of_the_three_runs": [round(sum(r) * 1e3, 2) for r in runs],
            "spot_calls": {"coarse": int(mp.big_spotforming_times), "fine": int(mp.spotforming_times)},
-           "talkers_found": len(out[0]), "setup_excluded_s": round(setup_s, 2)}
+           "talkers_found": len(out[0]), "setup_excluded_s": round(setup_s, 2), "srp_map": srp_rec}
     if sep_model is None:
         # no separation network behind sep_model: the figure is localisation only, stage 5 is not part of it
         del stages["joint_sep"]
@@ -225,6 +247,7 @@ def main():
     dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")       # where the exchanged tensors live
+    close_ranks.device = coll_dev
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -353,23 +376,33 @@ def main():
         roof = None
         peak = PEAK_TFLOPS[args.precision]
         if prof:
+            # the memory-bound passes (K1-K3 shift / normalise / preproc, GroupNorm + GLU, overlap-add,
+            # K9 energies) against the HBM roofline: algorithmic bytes of the launch / its event time
+            hbm = {k: {"ms_per_step": round(v["ms"] / args.steps, 4),
+                       "gbytes_per_launch": round(v["bytes"] / v["launches"] / 1e9, 4),
+                       "achieved_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                       "frac_of_8tbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if v.get("bytes", 0) > 0 and v["work"] == 0}
+            prof = {k: v for k, v in prof.items() if v["work"] > 0}
             name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
             ach = rec["work"] / (rec["ms"] * 1e-3) / 1e12
             tot_ms = sum(r["ms"] for r in prof.values())
             tot_work = sum(r["work"] for r in prof.values())
             # HBM / fabric bytes per launch of the dominant kernel need separate rocprofv3 --pmc passes (the guide's
-            # recipe): taken OFFLINE over this very command and kept in profiles/r2/traffic.json.  Only quoted when
+            # recipe): taken OFFLINE over this very command and kept in profiles/rN/traffic.json.  Only quoted when
             # the kernel and its per-launch batch are the ones of this run; otherwise null.
             traffic = traffic_src = None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r2", "traffic.json")))
-                if tj["kernel"] == name and tj["batch"] == min(args.batch, args.candidates) and T == 48000:
-                    traffic = int(tj["corrected_bytes_per_launch"])
-                    traffic_src = {"source": "offline: profiles/r2/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                             "`python bench.py`, same batch)", "algorithmic_bytes": int(tj["algorithmic_bytes"]),
-                                   "correction": tj["_correction"]}
-            except (OSError, KeyError, ValueError):
-                pass
+            for rnd in ("r3", "r2"):
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
+                    if tj["kernel"] == name and tj["batch"] == min(args.batch, args.candidates) and T == 48000:
+                        traffic = int(tj["corrected_bytes_per_launch"])
+                        traffic_src = {"source": f"offline: profiles/{rnd}/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                 "passes of `python bench.py`, same batch)",
+                                       "algorithmic_bytes": int(tj["algorithmic_bytes"]), "correction": tj["_correction"]}
+                        break
+                except (OSError, KeyError, ValueError):
+                    pass
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_detail": traffic_src,
                     "sustained_peak": ({"tflops": round(SUSTAINED_TFLOPS[args.precision], 1),
@@ -383,10 +416,22 @@ def main():
                                          "share_of_step_time": round(tot_ms * 1e-3 / dt, 3)},
                     "per_kernel": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                                        "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+                                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+                    "hbm_bound_kernels": {"peak_gbs": PEAK_HBM_GBS, "unit": "GB/s", "kernels": hbm,
+                                          "note": "algorithmic bytes (inputs read once + outputs written once) / HIP-event "
+                                                  "time of the launch; srp_map is reported under e2e_latency.srp_map"}}
         e2e = None
         if not args.no_e2e and world == 1:
             e2e = e2e_latency(model, build_sep_model(dev, args.precision), scene, dev)
+        if e2e is not None and not args.no_extras and T != 144000:
+            # the same pipeline on the reference-native clip: 3 s at 48 kHz (sep/helpers/constants.py:8)
+            try:
+                sc3 = make_scene(WORKLOAD_SEED, n_speakers=WORKLOAD_SPEAKERS, n_mics=7, T=144000, reverb=True)
+                extras["e2e_latency_T144000"] = e2e_latency(model, build_sep_model(dev, args.precision), sc3, dev)
+                extras["e2e_latency_T144000"]["note"] = "3 s at the reference's native 48 kHz, same scene seed, same protocol"
+            except Exception as exc:                      # an extra: reported, never fatal to the line
+                extras["e2e_latency_T144000"] = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()
         cpu = refstyle = None
         if world == 1:                                   # baselines: reported on rank 0 at N = 1 only
             if args.cpu_sample > 0:
@@ -401,8 +446,10 @@ def main():
             # figure of the same run is in `refstyle_gpu` (ratio = vs_refstyle_gpu)
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
             "config": {"workload": "configs[2] scene: 5-speaker reverberant mixture (image sources), 7 mics, T=%d samples "
-                                   "(3 s), fine-stage (Strict=1) candidate batch of one mixture, FULL spot net 47.27 M "
-                                   "params, seeded random weights" % T,
+                                   "(BASELINE's '3 s @ 16 kHz' sample count; the reference pipeline and this scene "
+                                   "generator run at 48 kHz, where it is a 1 s clip -- the reference-native 3 s is "
+                                   "extras.T144000), fine-stage (Strict=1) candidate batch of one mixture, FULL spot net "
+                                   "47.27 M params, seeded random weights" % T,
                        "candidates_per_gpu_per_step": args.candidates, "internal_batch": args.batch,
                        "gflop_per_candidate": round(fl["total"] / 1e9, 2), "parallelism": f"candidate-shard x{world}"},
             "effective_tflops": round(value * fl["total"] / 1e12, 2), "f16x3_overflow_count": overflow,
@@ -415,6 +462,7 @@ def main():
     # cluster heads); SRP-PHAT, the global clustering and the separation call are replica work.  Every rank takes
     # part.  The throughput line is complete before this starts: a watchdog turns a hung collective into a
     # reported error (rank 0 still prints the line) instead of a hung or failed run.
+    rc = 0
     if world > 1 and not args.no_e2e:
         import threading
         done = threading.Event()
@@ -424,7 +472,7 @@ def main():
                 if rank == 0:
                     line["e2e_latency"] = {"error": "multi-rank end-to-end measurement timed out"}
                     print(json.dumps(line), flush=True)
-                os._exit(0)
+                os._exit(EXIT_HUNG)                       # the line is out, the failure is in the status
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             from acousticswarms_speech_amd.shard import ShardedSpotModel
@@ -432,20 +480,39 @@ def main():
             e2e_sharded["ranks"] = world
             e2e_sharded["note"] = ("candidates of the coarse and the fine stage sharded over the ranks; SRP-PHAT, global "
                                    "clustering and the separation call replicated")
-        except Exception as exc:                          # reported, not fatal: the throughput line stands
+        except Exception as exc:                          # the throughput line stands, the run still fails
             e2e_sharded = {"error": f"{type(exc).__name__}: {exc}"}
+            rc = EXIT_E2E_FAILED
         done.set()
         if rank == 0:
             line["e2e_latency"] = e2e_sharded
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
-        # the line is out; a rank that failed above must not turn the closing barrier into a ten-minute hang
-        import threading
-        threading.Timer(60.0, lambda: os._exit(0)).start()
-        dist.barrier()
-        dist.destroy_process_group()
-        os._exit(0)
+        rc = close_ranks(dist, rc)
+    if rc:
+        raise SystemExit(rc)
+
+
+# exit statuses of a multi-rank run whose JSON line was still printed (the driver must see the failure)
+EXIT_HUNG, EXIT_E2E_FAILED, EXIT_CLOSE_HUNG = 2, 3, 4
+
+
+def close_ranks(dist, rc):
+    """Closing barrier of a multi-rank run.  The line is out; a rank that failed or left early must not turn
+    the barrier into a ten-minute hang, and must not look like success either: if the barrier does not
+    complete within a minute every waiting rank exits with EXIT_CLOSE_HUNG."""
+    import threading
+    guard = threading.Timer(float(os.environ.get("ASW_CLOSE_TIMEOUT_S", "60")), lambda: os._exit(EXIT_CLOSE_HUNG))
+    guard.daemon = True
+    guard.start()
+    dist.barrier()
+    # every rank learns whether any rank failed: the launcher's status is then the same whichever rank it reads
+    flag = torch.tensor([float(rc)], dtype=torch.float64, device=getattr(close_ranks, "device", "cpu"))
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    guard.cancel()
+    dist.destroy_process_group()
+    return int(flag.item())
 
 
 def build_sep_model(dev, precision):
@@ -494,18 +561,40 @@ def stub_main(args, world, rank):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ok = bool(np.array_equal(full, fake(None, offsets)))
+    line = None
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": round(n_total * args.steps / dt, 2), "unit": "candidates/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stub (no GPU, gloo)",
-                          "config": {"workload": "rank plumbing self-test", "world": scorer.world},
-                          "all_ranks_hold_all_energies": ok}), flush=True)
+        line = {"metric": "stub", "value": round(n_total * args.steps / dt, 2), "unit": "candidates/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stub (no GPU, gloo)",
+                "config": {"workload": "rank plumbing self-test", "world": scorer.world},
+                "all_ranks_hold_all_energies": ok}
+    rc = 0 if ok else EXIT_E2E_FAILED
     if dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if not ok:
-        raise SystemExit(3)
+        # second phase, watched exactly like the sharded end-to-end measurement of the real run: the line is
+        # complete before it starts; if a rank never joins the collective (ASW_STUB_FAULT_RANK: that rank skips
+        # it) rank 0 still prints the line and the run ends with a non-zero status
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("ASW_E2E_TIMEOUT_S", "240"))):
+                if rank == 0:
+                    line["e2e_latency"] = {"error": "multi-rank end-to-end measurement timed out"}
+                    print(json.dumps(line), flush=True)
+                os._exit(EXIT_HUNG)
+        threading.Thread(target=watchdog, daemon=True).start()
+        fault = os.environ.get("ASW_STUB_FAULT_RANK")
+        if fault is None or int(fault) != rank:
+            scorer.score(None, offsets, device="cpu")
+        done.set()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist:
+        close_ranks.device = "cpu"
+        rc = close_ranks(dist, rc)
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

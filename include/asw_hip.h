@@ -178,6 +178,9 @@ int asw_sep_infer(asw_sep* m, const float* mix, int M, int T, const int32_t* off
  * speakers: mix_norm [B][S*M][t] -> out [B][max(S, max_speakers)][t] (rows beyond S are zeros,
  * :486-488).  B*S <= 64. */
 int asw_sep_forward(asw_sep* m, const float* mix_norm, int B, int S, int M, int t, float* out, void* stream);
+/* The hyper-parameters the handle was created with (a caller that sizes `out` of asw_sep_forward from
+ * max_speakers must use the handle's value, not its own). */
+int asw_sep_get_config(const asw_sep* m, asw_sep_config* out);
 
 /* Debug/parity tap of the LAST call (channels-last [B*S][T_l][C] float32): "enc0".., "intra0"..,
  * "inter0".., "bottleneck", "dec0".. */
@@ -340,6 +343,39 @@ typedef struct asw_maskpath_args {
   float* taps;            /* [N/256][B][M_out][64] */
 } asw_maskpath_args;
 int asw_mask_path_f16x3(const asw_maskpath_args* args, void* stream);
+/* A stack of 1..3 consecutive 64-channel DilatedResidualLayers (DilatedResidualSequence,
+ * sep/training/SpeakerLocalization/network.py:50-82; the separation network uses the same classes) in
+ * ONE launch, f16x3 arithmetic: out_i = LayerNorm(ReLU(conv_{dil_i}(x_i) + bias_i) + x_i), x_{i+1} = out_i.
+ * The workgroup stages the rows the whole stack needs once; the intermediate tensors live in LDS only
+ * (halo recomputation: a tile of 256 rows of layer 0 yields 256 - 2 * sum_{i>0} dil_i (taps-1)/2 finished
+ * rows, so the later layers' dilations must be small: the call fails when fewer than 128 would be left).
+ * A single layer of dilation >= 7 runs on polyphase row sets.  Results agree with n_layers calls of
+ * asw_convgemm_f32 to fp32 rounding (the residual is taken from the fp16 hi + lo image: 2^-22 relative).
+ *   x / out [B][T][64] float32 (out must not alias x); layer[i]: weights Wt[64][taps*64] in fragment order
+ *   (asw_pack_fragments_f16), their shift, conv bias, LayerNorm affine.  glu_raw (optional, instead of x):
+ *   as asw_convgemm_args.glu_raw -- GroupNorm(2) + GLU applied while layer 0 stages its rows. */
+typedef struct asw_reslayer_desc {
+  const void* Wf_hi;
+  const void* Wf_lo;
+  const float* bias;
+  const float* ln_gamma;
+  const float* ln_beta;
+  int32_t dil;
+  int32_t w_shift;
+} asw_reslayer_desc;
+typedef struct asw_resstack_args {
+  const float* x;
+  float* out;
+  int32_t B, T, C, taps, n_layers;
+  int32_t precision;      /* 1 = f16x3, 2 = single-pass f16 */
+  float ln_eps;
+  asw_reslayer_desc layer[3];
+  const float* glu_raw;
+  const float* glu_mr;
+  const float* glu_gamma;
+  const float* glu_beta;
+} asw_resstack_args;
+int asw_resstack64_f16x3(const asw_resstack_args* args, void* stream);
 /* Host helper: split n fp32 weights into the fp16 hi/lo pair used by precision 1 with the
  * power-of-two pre-scale that keeps the lo parts out of the fp16 subnormal range; returns
  * the shift through *w_shift.  hi/lo: n uint16 each (host). */
@@ -384,7 +420,8 @@ int asw_overlap_add_parts(const float* D, int nparts, int B, int F, int ldd, int
                           const float* std, float* out, void* stream);
 
 /* Per-candidate energies: mean removal, power = sum x^2, power2 = max windowed RMS
- * (local_utils_3d.py:13-17,349-354).  scratch: [B][T+1] float64.  out [B][2] float64. */
+ * (local_utils_3d.py:13-17,349-354).  out [B][2] float64.  scratch is unused since ABI 3 (the prefix
+ * sums stay in registers / LDS) and may be NULL. */
 int asw_energies(const float* y, int B, int T, int window, double* scratch, double* out,
                  void* stream);
 

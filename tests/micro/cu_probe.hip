@@ -158,6 +158,50 @@ __global__ __launch_bounds__(256) void k_step(const half8* __restrict__ w, long 
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// ---- the same k-step on the 16x16x32 shape (same operand bytes per FLOP for the same 64 x 64 wave tile:
+//      per K = 32, 4 x {hi,lo} A fragments of 16 rows from LDS, 4 x {hi,lo} B fragments from global, 48 MFMAs)
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void k_step16(const half8* __restrict__ w, long span_frag, float* out, int iters, int lockstep) {
+  extern __shared__ __align__(16) char lds[];
+  for (int i = threadIdx.x; i < 64 * 1024 / 2; i += 256) {
+    unsigned h = (i + 7919u * blockIdx.x) * 2654435761u;
+    reinterpret_cast<_Float16*>(lds)[i] = (_Float16)(((int)(h >> 16) & 4095) * (1.0f / 2048.0f) - 1.0f);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const char* abase = lds + lane * 16;                 // conflict-free synthetic layout: the question here is the clock
+  floatx4 acc[TM][TN];
+  for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  half8 bh[TN], bl[TN], nh[TN], nl[TN];
+  long f = lockstep ? (long)wid * 2 * TN : ((long)blockIdx.x * 7 + wid * 1237) % span_frag;
+  for (int j = 0; j < TN; ++j) { nh[j] = w[(f + 2 * j) * 64 + lane]; nl[j] = w[(f + 2 * j + 1) * 64 + lane]; }
+  for (int it = 0; it < iters; ++it) {
+    half8 ah[TM], al[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const char* q = abase + ((i * 2 + (it & 7) * 8) * 1024);
+      ah[i] = *reinterpret_cast<const half8*>(q);
+      al[i] = *reinterpret_cast<const half8*>(q + 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { bh[j] = nh[j]; bl[j] = nl[j]; }
+    f += (lockstep ? 8 : 2) * TN; if (f + 8 * TN >= span_frag) f = lockstep ? (long)wid * 2 * TN : 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { nh[j] = w[(f + 2 * j) * 64 + lane]; nl[j] = w[(f + 2 * j + 1) * 64 + lane]; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+  }
+  float s = 0.f;
+  for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 static double time_ms(void (*launch)(), int reps = 3) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -217,6 +261,15 @@ template <int TM, int TN, int BSRC> void run_step() {
          100.0 * 32.0 / (cyc / (mf / (g_cus * 4))), mf * 32768 / 3 / ms * 1e-9);
 }
 
+template <int TM, int TN> void run_step16() {
+  auto L = []() { hipLaunchKernelGGL((k_step16<TM, TN>), dim3(g_cus * g_wgs), dim3(256), 64 * 1024, 0, g_w, g_span, g_out, g_iters, g_lock); };
+  const double ms = time_ms(L);
+  const double mf = (double)g_cus * g_wgs * 4 * g_iters * TM * TN * 3;
+  const double cyc = ms * 1e-3 * g_ghz * 1e9;
+  printf("k-step16x16x32%s TM=%d TN=%d B from global span %5.1f MB wgs/cu %d: %.1f cycles/MFMA/SIMD = %.0f%% of peak (%.0f f16x3-TFLOP/s)\n", g_lock ? " LOCKSTEP" : "", TM, TN,
+         g_span * 1024 / 1e6, g_wgs, cyc / (mf / (g_cus * 4)), 100.0 * 16.0 / (cyc / (mf / (g_cus * 4))), mf * 16384 / 3 / ms * 1e-9);
+}
+
 int main() {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
@@ -269,6 +322,7 @@ int main() {
       for (int lock : {0, 1}) {
         g_lock = lock;
         run_step<2, 2, 1>(); run_step<2, 4, 1>(); run_step<2, 1, 1>();
+        run_step16<4, 4>(); run_step16<4, 2>();          // wave tiles 64 x 64 and 64 x 32 on the 16x16x32 shape
       }
       g_lock = 0;
       if (quick) continue;

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in asw_hip.h but not exported"
     assert syms == set(native.SIGNATURES), (syms ^ set(native.SIGNATURES))
-    assert L.asw_abi_version() == 2
+    assert L.asw_abi_version() == 3
 
 
 def test_argument_errors_do_not_need_a_gpu():

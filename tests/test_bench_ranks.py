@@ -46,3 +46,14 @@ def test_rank_count_mismatch_fails():
     r = _run("--gpus", "2", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_rank_that_skips_a_collective_fails_the_run_but_the_line_is_printed():
+    """A rank that never joins a collective of the multi-rank end-to-end phase (here: rank 1 skips it) must not
+    end in status 0: the watchdog prints the already complete throughput line with an error note, and the run's
+    exit status is non-zero (bench.py EXIT_HUNG / EXIT_CLOSE_HUNG), so the driver sees the failure."""
+    r = _run("--gpus", "2", env_extra={"ASW_STUB_FAULT_RANK": "1", "ASW_E2E_TIMEOUT_S": "5", "ASW_CLOSE_TIMEOUT_S": "10"})
+    assert r.returncode != 0, r.stdout[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["all_ranks_hold_all_energies"] is True
+    assert "timed out" in line["e2e_latency"]["error"]

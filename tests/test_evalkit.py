@@ -120,6 +120,10 @@ def test_bss_eval_sdr_properties():
     assert np.all(np.asarray(outs) > np.asarray(ins) + 20) and np.all(np.asarray(osi) > np.asarray(isi) + 20)
 
 
+class _Sched:                                     # stands in for the lr scheduler the reference pickles into state.pt
+    pass
+
+
 def test_experiment_directory_loading(tmp_path):
     """load_model_from_exp (sep/helpers/utils.py:165-215): description.json -> network, best /
     last checkpoint selection, nothing unpickled."""
@@ -151,6 +155,21 @@ def test_experiment_directory_loading(tmp_path):
     with redirect_stdout(io.StringIO()):
         m = load_model_from_exp(str(exp), mode="last")
     np.testing.assert_array_equal(m._sd["preproc.weight"], make_spot_state_dict(SMALL, seed=102)["preproc.weight"])
+    # a state.pt the safe loader refuses (the reference pickles its scheduler object into it): 'best' must not
+    # silently become 'last'; the caller names the epoch or opts into the fallback
+    import pytest
+    torch.save({"val_losses": [0.9, 0.2, 0.5], "lr_sched": _Sched()}, exp / "checkpoints" / "state.pt")
+    with pytest.raises(RuntimeError, match="best_epoch"), redirect_stdout(io.StringIO()):
+        load_model_from_exp(str(exp), mode="best")
+    with redirect_stdout(io.StringIO()):
+        m = load_model_from_exp(str(exp), mode="best", best_epoch=1)
+    np.testing.assert_array_equal(m._sd["preproc.weight"], make_spot_state_dict(SMALL, seed=101)["preproc.weight"])
+    with redirect_stdout(io.StringIO()) as out:
+        m = load_model_from_exp(str(exp), mode="best", fallback_to_last=True)
+    assert "WARNING" in out.getvalue()
+    np.testing.assert_array_equal(m._sd["preproc.weight"], make_spot_state_dict(SMALL, seed=102)["preproc.weight"])
+    with pytest.raises(RuntimeError, match="growth"):
+        config_from_description({"model_name": "SpeakerLocalization", "model_params": {"growth": 1.5}})
     # separation experiment without state.pt: falls back to 'last'; 'new' loads nothing
     exp2 = tmp_path / "sepexp"
     (exp2 / "checkpoints").mkdir(parents=True)

@@ -4,7 +4,10 @@ configs[2]  5-speaker reverberant mixture, 7 mics: the complete search with the 
             against the CPU oracle behind the reference's shift_and_sep surface (T = 24 000 so the
             oracle finishes in minutes), plus the joint separation stage on the talkers found.
 configs[3]  a batch of 5-speaker mixtures: shard.localize_batch with the HIP model equals the
-            plain per-mixture loop, in one process and with two ranks sharing this box's GPU.
+            plain per-mixture loop, in one process and with two ranks sharing this box's GPU; and at
+            BASELINE size (64 mixtures, T = 48 000) on one GPU.
+configs[4]  16 microphones, dense width-2 TDoA lattice, FULL network, T = 48 000, 1 024 candidates:
+            size-independent properties of the hot call.
 flip rate   f16x3 (the bench arithmetic) against exact f32 on 16 full-size scenes (seeds
             1001-1008 three talkers, 1010-1017 five talkers + reverb, T = 48 000): every hard
             decision of the search -- coarse kept set, fine-stage accept / cluster membership,
@@ -168,6 +171,104 @@ def test_config3_mixture_batch_equals_plain_loop(full_weights):
             np.testing.assert_allclose(g[0], w[0], atol=1e-9)
             np.testing.assert_allclose(g[1], w[1], rtol=1e-6)
             assert g[2] == w[2] and g[3] == w[3]
+
+
+def test_config3_sixty_four_mixture_batch_at_size(full_weights):
+    """configs[3] at BASELINE size on this box's one GPU: 64 five-speaker mixtures (seeds 2000-2063, one array
+    geometry, T = 48 000) through shard.localize_batch -- the call that deals whole mixtures to ranks -- as a
+    property test: every mixture's result equals the plain per-mixture forward (positions, powers, names, spot-call
+    counts), everything finite, and the call counts stay inside the search's bounds (at most MAX_BIG_PATCH coarse
+    survivors, sep/helpers/constants.py:35).  Rates go to gpurun_out/config3_batch64.json."""
+    import time
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.joint import JointModel
+    from acousticswarms_speech_amd.shard import localize_batch
+    from acousticswarms_speech_amd.spot import SpotModel
+    first, scenes = _batch_scenes(64, T=48000)
+    mixes = [torch.from_numpy(s.mix) for s in scenes]
+    jm = JointModel(SpotModel(FULL, full_weights, batch_size=256, precision="f16x3").to("cuda"), None, device="cuda")
+    with redirect_stdout(io.StringIO()):
+        jm.setup(first.mic_positions, first.speaker_range)
+        jm.forward(mixes[0])                                              # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = localize_batch(jm, mixes)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        got = _batch_summary(out)
+        t0 = time.perf_counter()
+        want = []
+        for m in mixes:
+            patches, _al, _a, _d0, _d1, st = jm.forward(m)
+            want.append((np.array([p[0].center_pos() for p in patches]).reshape(-1, 3),
+                         np.array([p[2] for p in patches]), [p[3] for p in patches], int(st)))
+        torch.cuda.synchronize()
+        dt_loop = time.perf_counter() - t0
+    assert len(got) == 64
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g[0], w[0])
+        np.testing.assert_array_equal(g[1], w[1])
+        assert g[2] == w[2] and g[3] == w[3]
+        assert np.isfinite(g[0]).all() and np.isfinite(g[1]).all()
+        assert 1 <= g[3] <= 64 + 30 * 64                                   # coarse patches + <= 30 survivors x children
+    cands = sum(g[3] for g in got)
+    rec = {"workload": "64 five-speaker mixtures, 7 mics, T=48000, full search each, 1 GPU (configs[3])",
+           "mixtures_per_s": round(64 / dt, 2), "plain_loop_mixtures_per_s": round(64 / dt_loop, 2),
+           "spot_candidates": int(cands), "candidates_per_s_in_search": round(cands / dt, 1),
+           "talkers_found_mean": round(float(np.mean([len(g[2]) for g in got])), 2)}
+    with open(os.path.join(ROOT, "gpurun_out", "config3_batch64.json"), "w") as f:
+        json.dump(rec, f)
+    _log(f"config3 at size: {rec}")
+
+
+def test_config4_sixteen_mic_dense_lattice_at_size():
+    """configs[4] at BASELINE size: FULL network with 16 microphones, T = 48 000, 1 024 candidates of the dense
+    width-2 TDoA lattice (SRP-PHAT bypassed), where the oracle is too slow to be the checker -- size-independent
+    properties of the hot call: finite, run-to-run bit identity, a permuted list gives the permuted result bit for
+    bit, the internal batch size is invisible (1e-6), and the energies of the fast path equal the energies
+    recomputed from the returned waveforms of a slice (local_utils_3d.py:13-17,349-354)."""
+    import dataclasses
+    import time
+    from acousticswarms_speech_amd.config import FULL
+    from acousticswarms_speech_amd.dense_grid import dense_tdoa_candidates
+    from acousticswarms_speech_amd.scenes import make_scene
+    from acousticswarms_speech_amd.spot import SpotModel
+    from acousticswarms_speech_amd.weights import make_spot_state_dict
+    from oracle import spot_ref
+    cfg = dataclasses.replace(FULL, n_mics=16)
+    sc = make_scene(1010, 5, 16, 48000)
+    offs, _counts, _ = dense_tdoa_candidates(sc.mic_positions, sc.speaker_range, width=2, step=0.05, with_points=False)
+    assert len(offs) >= 10000 and offs.shape[1] == 15
+
+    class P:
+        def __init__(self, o):
+            self.sample_offset = o
+    step = len(offs) // 1024
+    pick = [P(o) for o in offs[::step][:1024]]
+    m = SpotModel(cfg, make_spot_state_dict(cfg, 1), batch_size=256, precision="f16x3").to("cuda")
+    mix = torch.from_numpy(sc.mix).cuda()
+    m.shift_and_score(mix, pick[:256], Strict=1)                          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    en = m.shift_and_score(mix, pick, Strict=1, keep_waveforms=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert en.shape == (1024, 2) and np.isfinite(en).all() and (en > 0).all()
+    np.testing.assert_array_equal(en, m.shift_and_score(mix, pick, Strict=1))
+    perm = np.random.default_rng(0).permutation(1024)
+    np.testing.assert_array_equal(m.shift_and_score(mix, [pick[i] for i in perm], Strict=1), en[perm])
+    m.set_batch_size(96)                                                  # ragged internal batches: 10 x 96 + 64
+    np.testing.assert_allclose(m.shift_and_score(mix, pick, Strict=1), en, rtol=1e-6)
+    sl = m.shift_and_score(mix, pick[:24], Strict=1, keep_waveforms=True)
+    waves = m.last_waveforms.cpu().numpy()
+    assert waves.shape == (24, 48000) and np.isfinite(waves).all()
+    np.testing.assert_allclose(sl, spot_ref.candidate_energies(waves, 12000), rtol=1e-4)
+    np.testing.assert_allclose(sl, en[:24], rtol=1e-6)
+    rec = {"workload": "16 mics, 5 talkers, dense width-2 TDoA lattice at 5 cm, T=48000, FULL net (configs[4])",
+           "lattice_candidates": int(len(offs)), "evaluated": 1024, "candidates_per_s": round(1024 / dt, 1)}
+    with open(os.path.join(ROOT, "gpurun_out", "config4_dense16.json"), "w") as f:
+        json.dump(rec, f)
+    _log(f"config4 at size: {rec}")
 
 
 # ------------------------------------------------------------------------------ flip rate
