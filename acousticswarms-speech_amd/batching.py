@@ -1,0 +1,244 @@
+"""Cross-mixture candidate batching (BASELINE configs[3]: a batch of mixtures per GPU).
+
+The reference fills its 128-wide network batches from ONE mixture at a time
+(sep/training/JointModel/network.py:75-96); a search issues a 30-candidate coarse call and then
+fine-stage chunks whose sizes follow the subdivision, so most internal batches run part empty and
+the GPU idles during the SRP-PHAT and clustering host work of the mixture.  Here several searches
+run concurrently -- one host thread per mixture, each with its own view of the (shared, read-only)
+geometry tables -- and every scoring request they make goes through a ``CandidateBatcher``: the
+requests of different mixtures are concatenated into one candidate stream with a per-candidate
+mixture index and evaluated by ONE ``asw_spot_shift_and_sep_multi`` launch sequence, as soon as a
+full internal batch is waiting or every live search is blocked on its request.  Each search sees
+its own slice of the result, so its decisions are those of the plain per-mixture loop.
+
+Only the spot network's workspace is shared between the searches, and only the batcher touches
+it (under its lock); everything else a search launches (SRP map, SI-SDR matrices) allocates its
+own buffers and runs in stream order on the device's default stream.
+"""
+import copy
+import threading
+import time
+
+import numpy as np
+
+from .spot import offsets_from_patches
+
+
+class _Request(object):
+    __slots__ = ("k", "offs", "key", "want_wave", "wave", "energy", "done", "error")
+
+    def __init__(self, k, offs, key, want_wave):
+        self.k, self.offs, self.key, self.want_wave = k, offs, key, want_wave
+        self.wave = self.energy = self.error = None
+        self.done = False
+
+
+class CandidateBatcher(object):
+    """Merges the scoring requests of ``n_workers`` concurrent searches over ``mix_stack [K,M,T]``
+    (cuda float32) into multi-mixture launches of ``model`` (a SpotModel on that device)."""
+
+    def __init__(self, model, mix_stack, n_workers, target=None):
+        self.model, self.mixes = model, mix_stack
+        self.live = int(n_workers)
+        self.target = int(target or model.batch_size)
+        self.cv = threading.Condition()
+        self.pending = []
+        self.blocked = 0
+        self.launches = 0
+        self.candidates = 0
+        self.sizes = []                                      # candidates per launch
+        self.host_s = 0.0                                    # host time spent enqueueing the launches
+        self.events = []                                     # (start, end) device events per launch (stats)
+
+    def proxy(self, k):
+        return MixtureScorer(self, int(k))
+
+    # ---- called by the searches -------------------------------------------------------------
+    def request(self, k, offs, strict, window, want_wave):
+        req = _Request(k, offs, (int(strict), int(window)), bool(want_wave))
+        with self.cv:
+            self.pending.append(req)
+            self.blocked += 1
+            self._pump()
+            while not req.done:
+                self.cv.wait()
+            self.blocked -= 1
+        if req.error is not None:
+            raise RuntimeError(f"batched scoring failed: {req.error}")
+        return req.wave, req.energy
+
+    def worker_done(self):
+        """A search has finished (or died): the others must not wait for it."""
+        with self.cv:
+            self.live -= 1
+            self._pump()
+
+    # ---- internals (lock held) -----------------------------------------------------------
+    def _pump(self):
+        while self.pending:
+            key = self.pending[0].key                       # oldest request decides which kind goes first
+            group = [r for r in self.pending if r.key == key]
+            total = sum(len(r.offs) for r in group)
+            if total < self.target and self.blocked < self.live:
+                return                                      # somebody is still on the host: wait for more candidates
+            self.pending = [r for r in self.pending if r.key != key]
+            self._launch(group, key)
+            self.cv.notify_all()
+
+    def _launch(self, group, key):
+        import torch
+        from . import native
+        try:
+            dev = self.mixes.device
+            offs = np.ascontiguousarray(np.concatenate([r.offs for r in group], axis=0))
+            idx = np.concatenate([np.full(len(r.offs), r.k, dtype=np.int32) for r in group])
+            assert idx.min() >= 0 and idx.max() < self.mixes.shape[0]
+            on_gpu = dev.type == "cuda"                      # (a CPU stand-in model drives this class in the host tests)
+            off_d, idx_d = torch.from_numpy(offs), torch.from_numpy(idx)
+            if on_gpu:
+                off_d = off_d.pin_memory().to(dev, non_blocking=True)
+                idx_d = idx_d.pin_memory().to(dev, non_blocking=True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            want_wave = any(r.want_wave for r in group)
+            t_host = time.perf_counter()
+            wave, en = self.model.shift_and_sep_device_multi(self.mixes, off_d, idx_d, key[0], want_wave=want_wave,
+                                                             want_energy=True, window=key[1])
+            self.host_s += time.perf_counter() - t_host
+            if on_gpu:
+                e1.record()
+                self.events.append((e0, e1))
+            self.sizes.append(len(offs))
+            if want_wave and on_gpu:
+                native.torch_ops().center_rows_(wave)       # the stage loops compare mean-removed outputs (Mic_Array.py:291)
+            elif want_wave:
+                wave -= wave.mean(dim=1, keepdim=True)
+            pos = 0
+            for r in group:
+                n = len(r.offs)
+                r.wave = wave[pos:pos + n] if r.want_wave else None
+                r.energy = en[pos:pos + n]
+                pos += n
+            self.launches += 1
+            self.candidates += pos
+        except Exception as exc:                             # every waiting search gets the error
+            for r in group:
+                r.error = f"{type(exc).__name__}: {exc}"
+        for r in group:
+            r.done = True
+
+
+class MixtureScorer(object):
+    """The spot-model surface one search uses (coarse ``shift_and_score``, fine ``shift_and_sep_resident``,
+    the device SI-SDR helpers), bound to mixture ``k`` of a batcher.  The mixture argument of the calls is
+    ignored: the candidates are scored against ``batcher.mixes[k]``."""
+
+    def __init__(self, batcher, k):
+        self.batcher, self.k = batcher, k
+        self.inner_model = batcher.model
+        self.device = batcher.model.device
+        self.batch_size = batcher.model.batch_size
+
+    def _offsets(self, patch_list):
+        return offsets_from_patches(patch_list, self.batcher.mixes.shape[1] - 1)
+
+    def shift_and_score(self, input_channels, patch_list, Strict=0, window=12000, keep_waveforms=False):
+        if len(patch_list) == 0:
+            return np.empty((0, 2), dtype=np.float64)
+        _w, en = self.batcher.request(self.k, self._offsets(patch_list), Strict, window, False)
+        return en.cpu().numpy()
+
+    def shift_and_sep_resident(self, input_channels, patch_list, Strict=0, window=12000, device_energies=False):
+        wave, en = self.batcher.request(self.k, self._offsets(patch_list), Strict, window, True)
+        return wave, (en if device_energies else en.cpu().numpy())
+
+    def shift_and_sep(self, input_channels, patch_list, Strict=0, save_input=False):
+        raise RuntimeError("a batched search scores through shift_and_score / shift_and_sep_resident only")
+
+    def pair_sisdr(self, waves):
+        return self.inner_model.pair_sisdr(waves)
+
+    def segment_sisdr(self, waves, segments):
+        return self.inner_model.segment_sisdr(waves, segments)
+
+
+def mixture_view(mic_array):
+    """A per-search view of a MicArray: the geometry tables (tens of MB, read-only) are shared, everything a
+    search writes -- the SRP map and its voxel image, counters, caches, the decision trace, the side stream --
+    is the view's own."""
+    v = copy.copy(mic_array)
+    v.SRP_node = copy.copy(mic_array.SRP_node)
+    v.SRP_node.POWER_MAP = mic_array.SRP_node.POWER_MAP.copy()
+    v._side_stream = None
+    v._seg_cache, v._dev_cache = {}, {}
+    v.trace = {"coarse_kept": [], "fine_clusters": {}, "final_clusters": []}
+    return v
+
+
+def search_batched(joint_model, mixes, concurrent=4):
+    """The complete localization search (SRP-PHAT -> coarse -> fine -> clustering) of every mixture in
+    ``mixes`` on this rank's GPU: ``concurrent`` worker threads pull mixtures from a queue -- a finished
+    search is replaced at once, so the GPU never waits for a group to drain -- and score through one
+    CandidateBatcher.  Returns the per-mixture result dicts of shard.localize_batch, in order, and a stats dict."""
+    import torch
+    spot = joint_model.spot_model
+    mp = joint_model.Mic_processor
+    assert mp is not None, "call JointModel.setup() first"
+    dev = spot.device
+    n = len(mixes)
+    results = [None] * n
+    hosts = [torch.as_tensor(m).to(dtype=torch.float32).cpu() for m in mixes]
+    stack = torch.stack(hosts).to(dev).contiguous()          # [K,M,T]: 1.3 MB per 7-mic, 48 000-sample mixture
+    n_workers = max(1, min(int(concurrent), n))
+    batcher = CandidateBatcher(spot, stack, n_workers)
+    errors, todo, todo_lock = [], list(range(n)), threading.Lock()
+
+    def search(k):
+        view, scorer = mixture_view(mp), batcher.proxy(k)
+        times = [0.0] * 5
+        t0 = time.time()
+        patch_list, _ = view.Apply_SRP_PHAT(hosts[k])
+        times[0] = time.time() - t0
+        patches, spot_times = [], 0
+        if len(patch_list) > 0:
+            t0 = time.time()
+            kept = view.Spotform_Big_Patch(stack[k], patch_list, scorer)
+            times[1] = time.time() - t0
+            if len(kept) > 0:
+                t0 = time.time()
+                pairs = view.Spotform_Small_Patch_Parallel(stack[k], kept, scorer)
+                times[2] = time.time() - t0
+                if len(pairs) > 0:
+                    t0 = time.time()
+                    _audio, patches, spot_times, _ = view.Clustering_new(pairs)
+                    times[3] = time.time() - t0
+        if len(patches) == 0:
+            patches, spot_times = [], 0                    # the reference's empty-result early returns (:151-199)
+        results[k] = {"centres": np.array([p[0].center_pos() for p in patches]).reshape(-1, 3),
+                      "powers": np.array([p[2] for p in patches]), "names": [p[3] for p in patches],
+                      "spot_times": spot_times, "times": times}
+
+    def work():
+        try:
+            while not errors:
+                with todo_lock:
+                    if not todo:
+                        break
+                    k = todo.pop(0)
+                search(k)
+        except BaseException as exc:                           # reported after the join; the others finish their mixture
+            errors.append(exc)
+        finally:
+            batcher.worker_done()
+
+    threads = [threading.Thread(target=work, name=f"asw-search-{w}") for w in range(n_workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    torch.cuda.synchronize(dev)
+    stats = {"launches": batcher.launches, "candidates": batcher.candidates, "launch_sizes": list(batcher.sizes),
+             "spot_gpu_s": sum(a.elapsed_time(b) for a, b in batcher.events) * 1e-3, "enqueue_host_s": batcher.host_s}
+    return results, stats

@@ -33,13 +33,16 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 
 // One workgroup per candidate: two passes over T (sum, then centred sum of squares),
 // double accumulation; the mixture stays in L2 across candidates.
-__global__ __launch_bounds__(1024) void shift_stats_kernel(const float* __restrict__ mix, int M, int T,
-                                                           const int32_t* __restrict__ offsets, int circular,
+__global__ __launch_bounds__(1024) void shift_stats_kernel(const float* __restrict__ mixes, int M, int T,
+                                                           const int32_t* __restrict__ offsets,
+                                                           const int32_t* __restrict__ mix_index, int circular,
                                                            float* __restrict__ mean_out,
                                                            float* __restrict__ std_out) {
   __shared__ int off[MAX_MICS];
   __shared__ double red[16];
   const int n = blockIdx.x;
+  // candidates of several mixtures in one launch: candidate n reads mixture mix_index[n] of [K][M][T]
+  const float* __restrict__ mix = mixes + (mix_index ? (long)mix_index[n] * M * T : 0);
   if (threadIdx.x < M) {
     int o = threadIdx.x == 0 ? 0 : offsets[(long)n * (M - 1) + threadIdx.x - 1];
     if (circular) { o %= T; if (o < 0) o += T; }
@@ -78,8 +81,9 @@ __global__ __launch_bounds__(1024) void shift_stats_kernel(const float* __restri
 // (2) thread = (row, float4 of output channels) does only the M fmas per channel from LDS
 // and a wave writes whole 256-byte channel rows back to back.
 template <bool SHIFTED>
-__global__ __launch_bounds__(256) void preproc_kernel(const float* __restrict__ src, int M, int T, int T_pad,
-                                                      const int32_t* __restrict__ offsets, int circular,
+__global__ __launch_bounds__(256) void preproc_kernel(const float* __restrict__ srcs, int M, int T, int T_pad,
+                                                      const int32_t* __restrict__ offsets,
+                                                      const int32_t* __restrict__ mix_index, int circular,
                                                       const float* __restrict__ mean, const float* __restrict__ stdv,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       int C, float* __restrict__ x0, float* __restrict__ refn,
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(256) void preproc_kernel(const float* __restrict__ 
   __shared__ float vs[64 * MAX_MICS];       // [row][m], rows_per_block <= 64
   __shared__ float ws[128 * MAX_MICS];      // preproc weights [C][M], C <= 128
   const int n = blockIdx.y;
+  const float* __restrict__ src = srcs + ((SHIFTED && mix_index) ? (long)mix_index[n] * M * T : 0);
   for (int i = threadIdx.x; i < C * M; i += blockDim.x) ws[i] = w[i];
   const int c4n = C >> 2;                   // float4 groups per row
   if (threadIdx.x < M) {
@@ -146,12 +151,17 @@ __global__ __launch_bounds__(256) void preproc_kernel(const float* __restrict__ 
 
 extern "C" int asw_shift_stats(const float* mix, int M, int T, const int32_t* offsets, int N, int circular,
                                float* mean, float* std, void* stream) {
+  return asw_shift_stats_multi(mix, M, T, offsets, nullptr, N, circular, mean, std, stream);
+}
+
+extern "C" int asw_shift_stats_multi(const float* mix, int M, int T, const int32_t* offsets, const int32_t* mix_index, int N,
+                                     int circular, float* mean, float* std, void* stream) {
   ASW_CHECK_ARG(mix && offsets && mean && std, "shift_stats: null pointer");
   ASW_CHECK_ARG(M >= 1 && M <= MAX_MICS && T >= 2, "shift_stats: M=%d T=%d unsupported", M, T);
   if (N == 0) return ASW_OK;
   // algorithmic bytes: the M x T mixture once (every candidate re-reads it from L2) + the statistics
   asw::ProfScope prof(asw::as_stream(stream), "shift_stats", 0.0, (double)M * T * 4 + (double)N * 8);
-  hipLaunchKernelGGL(shift_stats_kernel, dim3(N), dim3(1024), 0, asw::as_stream(stream), mix, M, T, offsets,
+  hipLaunchKernelGGL(shift_stats_kernel, dim3(N), dim3(1024), 0, asw::as_stream(stream), mix, M, T, offsets, mix_index,
                      circular, mean, std);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
@@ -161,6 +171,14 @@ extern "C" int asw_shift_norm_preproc(const float* mix, int M, int T, int T_pad,
                                       int circular, const float* mean, const float* std, const float* w,
                                       const float* b, int C, float* x0, float* refn, long refn_stride,
                                       void* stream) {
+  return asw_shift_norm_preproc_multi(mix, M, T, T_pad, offsets, nullptr, N, circular, mean, std, w, b, C, x0, refn,
+                                      refn_stride, stream);
+}
+
+extern "C" int asw_shift_norm_preproc_multi(const float* mix, int M, int T, int T_pad, const int32_t* offsets,
+                                            const int32_t* mix_index, int N, int circular, const float* mean,
+                                            const float* std, const float* w, const float* b, int C, float* x0, float* refn,
+                                            long refn_stride, void* stream) {
   ASW_CHECK_ARG(refn_stride >= T_pad, "shift_norm_preproc: refn_stride < T_pad");
   ASW_CHECK_ARG(mix && offsets && mean && std && w && b && x0 && refn, "shift_norm_preproc: null pointer");
   ASW_CHECK_ARG(M >= 1 && M <= MAX_MICS && T >= 1 && T_pad >= T && C % 4 == 0 && C > 0 && C <= 128,
@@ -170,7 +188,7 @@ extern "C" int asw_shift_norm_preproc(const float* mix, int M, int T, int T_pad,
   dim3 grid(asw::cdiv(T_pad, rows), N);
   // algorithmic bytes: the mixture once + the [N][T_pad][C] activation and the reference channel written
   asw::ProfScope prof(asw::as_stream(stream), "preproc", 0.0, (double)M * T * 4 + (double)N * T_pad * (C + 1) * 4);
-  hipLaunchKernelGGL(preproc_kernel<true>, grid, dim3(256), 0, asw::as_stream(stream), mix, M, T, T_pad, offsets,
+  hipLaunchKernelGGL(preproc_kernel<true>, grid, dim3(256), 0, asw::as_stream(stream), mix, M, T, T_pad, offsets, mix_index,
                      circular, mean, std, w, b, C, x0, refn, refn_stride, rows);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
@@ -186,7 +204,7 @@ extern "C" int asw_pad_preproc(const float* x, int B, int M, int t, int T_pad, c
   const int rows = 64;
   dim3 grid(asw::cdiv(T_pad, rows), B);
   hipLaunchKernelGGL(preproc_kernel<false>, grid, dim3(256), 0, asw::as_stream(stream), x, M, t, T_pad,
-                     (const int32_t*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, w, b, C, x0, refn,
+                     (const int32_t*)nullptr, (const int32_t*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, w, b, C, x0, refn,
                      refn_stride, rows);
   ASW_LAUNCH_CHECK();
   return ASW_OK;

@@ -54,6 +54,16 @@ struct LayerDev {
   float scale;                           // 2^-w_shift
 };
 
+#ifdef ASW_PHASE_TIMING
+// Diagnostic build only (tests/micro/resstack_phases.py): cycles wave 0 of every workgroup spends per phase, summed
+// over workgroups: [0] staging, [1] layer-0 k-loop, [2] layer-0 epilogue + hand-over, [3] layer-1 k-loop,
+// [4] layer-1 epilogue + stores, [5] workgroups.
+__device__ unsigned long long g_rs_cycles[6] = {0, 0, 0, 0, 0, 0};
+#define RS_MARK(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define RS_MARK(var)
+#endif
+
 struct KArgs {
   const float* x;
   float* out;
@@ -157,6 +167,7 @@ void resstack64_kernel(const KArgs p) {
   const int RJ = BMJ + taps - 1;                        // polyphase: image rows per phase
   const int R_img = POLY ? PH * RJ : R0 + 2 * pad0;
 
+  RS_MARK(t_start);
   // ---- per-layer vectors -> LDS
   for (int i = tid; i < NL * 3 * 16; i += NTHR) {
     const int li = i / 48, w = (i - li * 48) / 16, c4 = i & 15;
@@ -177,12 +188,15 @@ void resstack64_kernel(const KArgs p) {
       ggg = *reinterpret_cast<const float4*>(p.glu_gamma + C + sc4 * 4);
       gbg = *reinterpret_cast<const float4*>(p.glu_beta + C + sc4 * 4);
     }
-    for (int r0 = 0; r0 < R_img; r0 += SROWS * 8) {
-      float4 buf[8];
-      float4 gate[GLU ? 8 : 1];
-      bool okr[GLU ? 8 : 1];
+    // the whole image is requested before the first row is converted: one exposed memory latency per tile (with 8
+    // rows per thread in flight the three rounds of a 262-row image took 17 % of a workgroup's time)
+    constexpr int SU = GLU ? 9 : 18;
+    for (int r0 = 0; r0 < R_img; r0 += SROWS * SU) {
+      float4 buf[SU];
+      float4 gate[GLU ? SU : 1];
+      bool okr[GLU ? SU : 1];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int row = r0 + u * SROWS + srow;
         int g;
         bool ok = row < R_img;
@@ -206,7 +220,7 @@ void resstack64_kernel(const KArgs p) {
       if (GLU) {
         // the arithmetic of gn_glu_kernel, expression for expression; rows outside the sequence stay zero
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < SU; ++u) {
           float4 o;
 #define ASW_GLU(f)                                                       \
   {                                                                      \
@@ -219,7 +233,7 @@ void resstack64_kernel(const KArgs p) {
         }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int row = r0 + u * SROWS + srow;
         if (row < R_img) {
           half4 hi, lo;
@@ -231,6 +245,11 @@ void resstack64_kernel(const KArgs p) {
     }
   }
   __syncthreads();
+  RS_MARK(t_staged);
+#ifdef ASW_PHASE_TIMING
+  unsigned long long t_marks[2 * MAXL + 1];
+  t_marks[0] = t_staged;
+#endif
 
   const int h = lane >> 5;
   floatx16 acc[TM][2];
@@ -245,7 +264,7 @@ void resstack64_kernel(const KArgs p) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.f;        // (all of acc defined on every path: it stays in registers)
     // image row of output row `trow` at tap 0
     auto img_row = [&](int trow) { return POLY ? (trow / BMJ) * RJ + trow % BMJ : trow; };
     // this wave's first nf (<= TM) fragments: one k-loop instantiation per count (wave-uniform choice)
@@ -271,6 +290,13 @@ void resstack64_kernel(const KArgs p) {
         if (nf == 3) run(std::integral_constant<int, 3>{});
       }
     }
+#ifdef ASW_PHASE_TIMING
+    {
+      float sink = acc[0][0][0];
+      asm volatile("" ::"v"(sink));                     // the stamp waits for the MFMAs
+      t_marks[2 * li + 1] = __builtin_readcyclecounter();
+    }
+#endif
     // ---- epilogue in registers: + bias, ReLU, + residual (the layer's own input, from the image), LayerNorm
     const float* tb = tab + li * 192;
     const int cpad = POLY ? (taps - 1) / 2 : Ld.pad;    // image row of the residual = tap-0 row + centre tap
@@ -376,8 +402,26 @@ void resstack64_kernel(const KArgs p) {
     }
   };
   layer(std::integral_constant<int, 0>{});
+#ifdef ASW_PHASE_TIMING
+  t_marks[2] = __builtin_readcyclecounter();
+#endif
   if constexpr (NL > 1) layer(std::integral_constant<int, 1>{});
   if constexpr (NL > 2) layer(std::integral_constant<int, 2>{});
+#ifdef ASW_PHASE_TIMING
+  if (threadIdx.x == 0 && NL <= 2) {
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    atomicAdd(&g_rs_cycles[0], t_staged - t_start);
+    atomicAdd(&g_rs_cycles[1], t_marks[1] - t_marks[0]);
+    if (NL == 1) {
+      atomicAdd(&g_rs_cycles[4], t_end - t_marks[1]);
+    } else {
+      atomicAdd(&g_rs_cycles[2], t_marks[2] - t_marks[1]);
+      atomicAdd(&g_rs_cycles[3], t_marks[3] - t_marks[2]);
+      atomicAdd(&g_rs_cycles[4], t_end - t_marks[3]);
+    }
+    atomicAdd(&g_rs_cycles[5], 1ull);
+  }
+#endif
 }
 
 template <int NL, int NW, int TM, int PH, bool POLY, bool GLU, int QD>
@@ -445,6 +489,17 @@ int dispatch(const asw_resstack_args& a, KArgs& k, bool glu, double flops, hipSt
 }
 
 }  // namespace
+
+#ifdef ASW_PHASE_TIMING
+extern "C" int asw_debug_resstack_cycles(unsigned long long* out6, int reset) {
+  ASW_HIP(hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_rs_cycles), 6 * sizeof(unsigned long long)));
+  if (reset) {
+    const unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+    ASW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rs_cycles), z, sizeof z));
+  }
+  return ASW_OK;
+}
+#endif
 
 extern "C" int asw_resstack64_f16x3(const asw_resstack_args* args, void* stream) {
   ASW_CHECK_ARG(args != nullptr, "resstack: null args");

@@ -572,7 +572,15 @@ extern "C" int asw_spot_finalize(asw_spot* m) {
 extern "C" int asw_spot_shift_and_sep(asw_spot* m, const float* mix, int M, int T, const int32_t* offsets, int N,
                                       int strict, int circular, float* out_wave, double* out_energy,
                                       int energy_window, void* stream) {
+  return asw_spot_shift_and_sep_multi(m, mix, 1, M, T, offsets, nullptr, N, strict, circular, out_wave, out_energy,
+                                      energy_window, stream);
+}
+
+extern "C" int asw_spot_shift_and_sep_multi(asw_spot* m, const float* mix, int K, int M, int T, const int32_t* offsets,
+                                            const int32_t* mix_index, int N, int strict, int circular, float* out_wave,
+                                            double* out_energy, int energy_window, void* stream) {
   int rc = check_ready(m);
+  ASW_CHECK_ARG(K >= 1 && (K == 1 || mix_index != nullptr), "shift_and_sep: K=%d mixtures need a mix_index array", K);
   if (rc) return rc;
   ASW_CHECK_ARG(N >= 0, "shift_and_sep: N=%d", N);
   if (N == 0) return ASW_OK;
@@ -612,11 +620,12 @@ extern "C" int asw_spot_shift_and_sep(asw_spot* m, const float* mix, int M, int 
       hipStream_t q = st[k % lanes];
       p.B = B;
       const int32_t* off = offsets + (size_t)i0 * (M - 1);
+      const int32_t* mi = mix_index ? mix_index + i0 : nullptr;
       ASW_HIP(hipMemsetAsync(p.refn, 0, (size_t)B * p.RL * sizeof(float), q));
       int r;
-      if ((r = asw_shift_stats(mix, M, T, off, B, circular, p.mean, p.stdv, q))) return r;
-      if ((r = asw_shift_norm_preproc(mix, M, T, p.Tp, off, B, circular, p.mean, p.stdv, m->pre_w.p, m->pre_b.p, C,
-                                      p.X[0], p.refn + pad_l, p.RL, q)))
+      if ((r = asw_shift_stats_multi(mix, M, T, off, mi, B, circular, p.mean, p.stdv, q))) return r;
+      if ((r = asw_shift_norm_preproc_multi(mix, M, T, p.Tp, off, mi, B, circular, p.mean, p.stdv, m->pre_w.p, m->pre_b.p, C,
+                                            p.X[0], p.refn + pad_l, p.RL, q)))
         return r;
       float* y = out_wave ? out_wave + (size_t)i0 * T : p.ywave;
       if ((r = run_network(m, p, gs, p.mean, p.stdv, y, q))) return r;

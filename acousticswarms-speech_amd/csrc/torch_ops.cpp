@@ -79,6 +79,34 @@ std::tuple<Tensor, Tensor> spot_shift_and_sep(int64_t model, const Tensor& mix, 
   return {wave, energy};
 }
 
+// candidates of several mixtures in one call: mix [K, M, T], mix_index [N] (values in [0, K): built and checked on the host
+// by the caller -- reading them back here would stall the stream)
+std::tuple<Tensor, Tensor> spot_shift_and_sep_multi(int64_t model, const Tensor& mix, const Tensor& offsets,
+                                                    const Tensor& mix_index, int64_t strict, bool circular, bool want_wave,
+                                                    bool want_energy, int64_t window) {
+  TORCH_CHECK(model != 0, "spot_shift_and_sep_multi: null model handle");
+  need(mix, "mix", at::kFloat, 3);
+  need(offsets, "offsets", at::kInt, 2);
+  need(mix_index, "mix_index", at::kInt, 1);
+  same_device(mix, offsets, "mix and offsets");
+  same_device(mix, mix_index, "mix and mix_index");
+  const int K = checked_int(mix.size(0), "K"), M = checked_int(mix.size(1), "M"), T = checked_int(mix.size(2), "T");
+  const int N = checked_int(offsets.size(0), "N");
+  TORCH_CHECK(K >= 1 && offsets.size(1) == M - 1 && mix_index.size(0) == N, "offsets must be [N, M-1] and mix_index [N]");
+  Tensor wave = at::empty({want_wave ? N : 0, T}, mix.options());
+  Tensor energy = at::empty({want_energy ? N : 0, 2}, mix.options().dtype(at::kDouble));
+  if (N == 0) return {wave, energy};
+  Launch l(mix);
+  check_status(asw_spot_shift_and_sep_multi(reinterpret_cast<asw_spot*>(model), mix.data_ptr<float>(), K, M, T,
+                                            offsets.data_ptr<int32_t>(), mix_index.data_ptr<int32_t>(), N,
+                                            checked_int(strict, "strict"), circular ? 1 : 0,
+                                            want_wave ? wave.data_ptr<float>() : nullptr,
+                                            want_energy ? energy.data_ptr<double>() : nullptr, checked_int(window, "window"),
+                                            l.stream),
+               "asw_spot_shift_and_sep_multi");
+  return {wave, energy};
+}
+
 Tensor spot_forward(int64_t model, const Tensor& mix_norm, double w0, double w1) {
   TORCH_CHECK(model != 0, "spot_forward: null model handle");
   need(mix_norm, "mix", at::kFloat, 3);
@@ -254,6 +282,8 @@ Tensor sep_forward(int64_t model, const Tensor& mix_norm, int64_t n_speakers, in
 TORCH_LIBRARY(asw, m) {
   m.def("spot_shift_and_sep(int model, Tensor mix, Tensor offsets, int strict, bool circular, bool want_wave, "
         "bool want_energy, int window) -> (Tensor, Tensor)");
+  m.def("spot_shift_and_sep_multi(int model, Tensor mix, Tensor offsets, Tensor mix_index, int strict, bool circular, "
+        "bool want_wave, bool want_energy, int window) -> (Tensor, Tensor)");
   m.def("spot_forward(int model, Tensor mix, float w0, float w1) -> Tensor");
   m.def("shift_norm_preproc(Tensor mix, Tensor offsets, Tensor w, Tensor b, int T_pad, bool circular) -> "
         "(Tensor, Tensor, Tensor, Tensor)");
@@ -269,6 +299,7 @@ TORCH_LIBRARY(asw, m) {
 
 TORCH_LIBRARY_IMPL(asw, CUDA, m) {
   m.impl("spot_shift_and_sep", &spot_shift_and_sep);
+  m.impl("spot_shift_and_sep_multi", &spot_shift_and_sep_multi);
   m.impl("spot_forward", &spot_forward);
   m.impl("shift_norm_preproc", &shift_norm_preproc);
   m.impl("energies", &energies);

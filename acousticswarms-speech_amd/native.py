@@ -160,6 +160,8 @@ SIGNATURES = {
     "asw_pack_fragments_f16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(c_int32)]),
     "asw_spot_shift_and_sep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_int, c_void_p]),
+    "asw_spot_shift_and_sep_multi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                             c_void_p, c_void_p, c_int, c_void_p]),
     "asw_spot_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_void_p, c_void_p]),
     "asw_spot_set_fused_mask": (c_int, [c_void_p, c_int]),
     "asw_spot_get_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]),
@@ -185,6 +187,9 @@ SIGNATURES = {
     "asw_shift_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asw_shift_norm_preproc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p]),
+    "asw_shift_stats_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "asw_shift_norm_preproc_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p]),
     "asw_pad_preproc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_long, c_void_p]),
     "asw_convgemm_f32": (c_int, [POINTER(ConvGemmArgs), c_void_p]),

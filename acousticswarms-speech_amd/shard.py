@@ -213,13 +213,18 @@ class ShardedSpotModel:
         return sorted(merged, key=key)
 
 
-def localize_batch(joint_model, mixes, group=None):
+def localize_batch(joint_model, mixes, group=None, concurrent=4):
     """A batch of mixtures over the ranks of one node (BASELINE config "batch of 64 mixtures"):
     with at least as many mixtures as ranks the cheapest partition is by whole mixture --
     contiguous balanced blocks, each rank runs the complete search of its mixtures on its own
     GPU with no per-candidate traffic -- followed by ONE object all-gather of the per-mixture
     results.  (Fewer mixtures than ranks: wrap the spot model in ``ShardedSpotModel`` instead,
     which shards the candidates of a single mixture.)
+
+    On a rank, the searches of its mixtures run ``concurrent`` at a time and share their network
+    launches (batching.search_batched: one candidate stream with a per-candidate mixture index, so the
+    internal batches stay full and one search's host stages overlap the others' GPU work) when the spot
+    model is the HIP model; ``concurrent=1`` or any other duck-typed model gives the plain loop.
 
     ``joint_model.spot_model`` must be the plain per-rank model here.  Returns, on every rank and
     in mixture order, a list of dicts {centres [K,3], powers [K], names, spot_times, times[5]}."""
@@ -230,13 +235,23 @@ def localize_batch(joint_model, mixes, group=None):
     if getattr(joint_model.spot_model, "world", 1) > 1:
         raise RuntimeError("localize_batch shards by mixture: pass the un-sharded per-rank spot model")
     b = shard_bounds(len(mixes), world)
+    mine = list(range(b[rank], b[rank + 1]))
+    spot = joint_model.spot_model
+    batched = (concurrent > 1 and len(mine) > 1 and hasattr(spot, "shift_and_sep_device_multi")
+               and getattr(getattr(spot, "device", None), "type", None) == "cuda")
     local = []
-    for k in range(b[rank], b[rank + 1]):
-        patches, _audio_loc, _audio, _d0, _d1, spot_times = joint_model.forward(mixes[k])
-        local.append((k, {"centres": np.array([p[0].center_pos() for p in patches]).reshape(-1, 3),
-                          "powers": np.array([p[2] for p in patches]),
-                          "names": [p[3] for p in patches],
-                          "spot_times": spot_times, "times": list(joint_model.times)}))
+    if batched:
+        from .batching import search_batched
+        res, stats = search_batched(joint_model, [mixes[k] for k in mine], concurrent=concurrent)
+        localize_batch.last_stats = stats                    # diagnostic: launches, candidates, GPU seconds inside them
+        local = list(zip(mine, res))
+    else:
+        for k in mine:
+            patches, _audio_loc, _audio, _d0, _d1, spot_times = joint_model.forward(mixes[k])
+            local.append((k, {"centres": np.array([p[0].center_pos() for p in patches]).reshape(-1, 3),
+                              "powers": np.array([p[2] for p in patches]),
+                              "names": [p[3] for p in patches],
+                              "spot_times": spot_times, "times": list(joint_model.times)}))
     if world == 1:
         return [r for _k, r in local]
     box = [None] * world

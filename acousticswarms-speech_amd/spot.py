@@ -156,6 +156,21 @@ class SpotModel:
                                                          bool(want_wave), bool(want_energy), int(window))
         return (wave if want_wave else None), (en if want_energy else None)
 
+    def shift_and_sep_device_multi(self, mix_stack, offsets_dev, mix_index_dev, strict: int = 0, want_wave: bool = True,
+                                   want_energy: bool = False, window: int = 12000, circular: bool = True):
+        """The same call over candidates of several mixtures (torch.ops.asw.spot_shift_and_sep_multi):
+        mix_stack [K,M,T] float32 cuda, offsets_dev [N,M-1] int32, mix_index_dev [N] int32 with values in [0,K)
+        (the caller builds it on the host and guarantees the range)."""
+        import torch
+        self._need()
+        assert mix_stack.dim() == 3 and mix_stack.dtype == torch.float32 and mix_stack.is_contiguous() and mix_stack.is_cuda
+        assert offsets_dev.dtype == torch.int32 and offsets_dev.is_contiguous() and offsets_dev.is_cuda
+        assert mix_index_dev.dtype == torch.int32 and mix_index_dev.is_contiguous() and mix_index_dev.is_cuda
+        wave, en = native.torch_ops().spot_shift_and_sep_multi(self._h.value, mix_stack, offsets_dev, mix_index_dev,
+                                                               int(strict), bool(circular), bool(want_wave),
+                                                               bool(want_energy), int(window))
+        return (wave if want_wave else None), (en if want_energy else None)
+
     # ---- reference call surface ---------------------------------------------------
     def shift_and_sep(self, input_channels, patch_list, Strict: int = 0, save_input: bool = False) -> np.ndarray:
         """Drop-in for DataParallelSpotModel.shift_and_sep: returns ndarray [N,T] float32."""

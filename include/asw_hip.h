@@ -109,6 +109,17 @@ int asw_spot_shift_and_sep(asw_spot* m, const float* mix, int M, int T,
                            float* out_wave, double* out_energy, int energy_window,
                            void* stream);
 
+/* The same call over the candidates of SEVERAL mixtures in one stream (the reference fills its 128-wide
+ * batches from one mixture at a time, sep/training/JointModel/network.py:75-96; a batch of mixtures --
+ * BASELINE configs[3] -- keeps the internal batches full when its searches are interleaved):
+ *   mix [K][M][T] float32 device, mix_index [N] int32 device (candidate n reads mixture mix_index[n], values in
+ *   [0, K); may be NULL when K == 1).  The mix_index values are NOT range-checked on the device: the caller
+ *   guarantees them.  Everything else as asw_spot_shift_and_sep; each candidate's result is the one it has in a
+ *   single-mixture call of the same internal batch size. */
+int asw_spot_shift_and_sep_multi(asw_spot* m, const float* mix, int K, int M, int T, const int32_t* offsets,
+                                 const int32_t* mix_index, int N, int strict, int circular, float* out_wave,
+                                 double* out_energy, int energy_window, void* stream);
+
 /* Network.forward (sep/training/SpeakerLocalization/network.py:363-405) on already
  * normalised input: mix [B][M][t], window_embedding host [2] shared by the batch ->
  * out [B][t]. */
@@ -238,6 +249,15 @@ int asw_shift_norm_preproc(const float* mix, int M, int T, int T_pad, const int3
                            int N, int circular, const float* mean, const float* std,
                            const float* w, const float* b, int C, float* x0, float* refn,
                            long refn_stride, void* stream);
+
+/* The two calls above over candidates of several mixtures: mix [K][M][T], candidate n reads mixture
+ * mix_index[n] (int32 device [N], values in [0, K), not range-checked; NULL = mixture 0 for every candidate). */
+int asw_shift_stats_multi(const float* mix, int M, int T, const int32_t* offsets, const int32_t* mix_index, int N,
+                          int circular, float* mean, float* std, void* stream);
+int asw_shift_norm_preproc_multi(const float* mix, int M, int T, int T_pad, const int32_t* offsets,
+                                 const int32_t* mix_index, int N, int circular, const float* mean, const float* std,
+                                 const float* w, const float* b, int C, float* x0, float* refn, long refn_stride,
+                                 void* stream);
 
 /* Normalised input variant used by asw_spot_forward: x [B][M][t] -> x0, refn. */
 int asw_pad_preproc(const float* x, int B, int M, int t, int T_pad, const float* w,

@@ -21,8 +21,8 @@ from acousticswarms_speech_amd.spot import SpotModel  # noqa: E402
 from acousticswarms_speech_amd.weights import make_spot_state_dict  # noqa: E402
 
 
-def main(n_mix=64, T=48000):
-    model = SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=128, precision="f16x3").to("cuda")
+def main(n_mix=64, T=48000, concurrent=4, batch=256):
+    model = SpotModel(FULL, make_spot_state_dict(FULL, 5), batch_size=batch, precision="f16x3").to("cuda")
     jm = JointModel(model, None, device="cuda")
     sc0 = make_scene(2000, 5, 7, T)
     # one array geometry for the whole batch (a recording session): setup() once, excluded like the reference's
@@ -33,18 +33,23 @@ def main(n_mix=64, T=48000):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     with redirect_stdout(io.StringIO()):
-        out = localize_batch(jm, mixes)
+        out = localize_batch(jm, mixes, concurrent=concurrent)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     cands = sum(r["spot_times"] for r in out)
     stages = np.array([r["times"] for r in out]).sum(0)
     print(json.dumps({"workload": "64 five-speaker mixtures, 7 mics, T=%d, full search each, 1 GPU" % T,
+                      "concurrent_searches": concurrent, "internal_batch": batch,
                       "mixtures_per_s": round(n_mix / dt, 2), "s_total": round(dt, 2),
                       "spot_candidates": int(cands), "candidates_per_s_in_search": round(cands / dt, 1),
+                      "batcher": (lambda st: None if st is None else {
+                          "launches": st["launches"], "spot_gpu_s": round(st["spot_gpu_s"], 2), "enqueue_host_s": round(st["enqueue_host_s"], 2),
+                          "median_launch": int(np.median(st["launch_sizes"])), "max_launch": int(max(st["launch_sizes"]))})(
+                          getattr(localize_batch, "last_stats", None) if concurrent > 1 else None),
                       "talkers_found_mean": round(float(np.mean([len(r["names"]) for r in out])), 2),
                       "stage_seconds": {k: round(float(v), 2) for k, v in
                                         zip(["srp_phat", "coarse", "fine", "clustering", "joint_sep"], stages)}}))
 
 
 if __name__ == "__main__":
-    main()
+    main(concurrent=int(sys.argv[1]) if len(sys.argv) > 1 else 4)

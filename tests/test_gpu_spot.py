@@ -289,3 +289,32 @@ def test_two_lanes_give_the_single_lane_result():
         for _ in range(3):
             w2, e2 = two.shift_and_sep_device(mix, offs, strict=1, want_wave=True, want_energy=True, window=1000)
             assert torch.equal(w1, w2) and torch.equal(e1, e2)
+
+
+def test_multi_mixture_call_equals_single_mixture_calls():
+    """asw_spot_shift_and_sep_multi (candidates of several mixtures in one stream, BASELINE configs[3]): with every
+    candidate pointing at mixture k the call is the single-mixture call on mixture k, bit for bit (same internal
+    batches); with mixed indices every candidate still gets its own mixture's result (1e-6: the internal batch it
+    lands in differs); waveforms and energies both."""
+    from acousticswarms_speech_amd.config import SMALL
+    from acousticswarms_speech_amd.scenes import make_scene, random_offsets
+    m = _model(SMALL, 3, batch=5)
+    m.set_precision("f16x3")
+    T = 4000
+    stack = torch.stack([torch.from_numpy(make_scene(50 + k, 2, 7, T).mix) for k in range(3)]).cuda().contiguous()
+    offs = torch.from_numpy(random_offsets(9, 11, 6, 60)).cuda()
+    singles = []
+    for k in range(3):
+        w, e = m.shift_and_sep_device(stack[k].contiguous(), offs, strict=1, want_wave=True, want_energy=True, window=1000)
+        idx = torch.full((11,), k, dtype=torch.int32, device="cuda")
+        w2, e2 = m.shift_and_sep_device_multi(stack, offs, idx, strict=1, want_wave=True, want_energy=True, window=1000)
+        assert torch.equal(w, w2) and torch.equal(e, e2)
+        singles.append((w.cpu().numpy(), e.cpu().numpy()))
+    idx = torch.tensor([0, 2, 1, 1, 0, 2, 2, 0, 1, 0, 2], dtype=torch.int32, device="cuda")
+    w, e = m.shift_and_sep_device_multi(stack, offs, idx, strict=1, want_wave=True, want_energy=True, window=1000)
+    w, e = w.cpu().numpy(), e.cpu().numpy()
+    assert np.isfinite(w).all()
+    for n, k in enumerate(idx.tolist()):
+        np.testing.assert_allclose(w[n], singles[k][0][n], rtol=0, atol=1e-5 * float(np.abs(singles[k][0][n]).max()))
+        np.testing.assert_allclose(e[n], singles[k][1][n], rtol=1e-5)
+    assert not np.allclose(singles[0][0], singles[1][0])          # the three mixtures really differ
