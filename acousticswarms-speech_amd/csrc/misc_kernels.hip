@@ -633,14 +633,19 @@ extern "C" int asw_gn_finalize(const float* stats, int n_partials, int B, int T,
   return ASW_OK;
 }
 
-namespace asw { int attention_mfma(const float* qkv, int B, int L, int d, int nhead, float* ctx, hipStream_t s); }
+namespace asw { int attention_mfma(const float* qkv, int B, int L, int d, int nhead, float* ctx, hipStream_t s, int precision); }
 
 extern "C" int asw_attention(const float* qkv, int B, int L, int d, int nhead, float* ctx, void* stream) {
+  return asw_attention_prec(qkv, B, L, d, nhead, 0, ctx, stream);
+}
+
+extern "C" int asw_attention_prec(const float* qkv, int B, int L, int d, int nhead, int precision, float* ctx, void* stream) {
   ASW_CHECK_ARG(qkv && ctx, "attention: null pointer");
+  ASW_CHECK_ARG(precision >= 0 && precision <= 2, "attention: precision %d", precision);
   ASW_CHECK_ARG(B > 0 && L > 0 && nhead > 0 && d % nhead == 0, "attention: bad shape");
   ASW_CHECK_ARG(B <= 65535 && nhead <= 65535, "attention: grid too large");
   {
-    const int rc = asw::attention_mfma(qkv, B, L, d, nhead, ctx, asw::as_stream(stream));   // head_dim 128: MFMA kernels
+    const int rc = asw::attention_mfma(qkv, B, L, d, nhead, ctx, asw::as_stream(stream), precision);   // head_dim 128: MFMA kernels
     if (rc != 1) return rc;
   }
   const int hd = d / nhead;

@@ -319,7 +319,7 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
     TfLayer& t = m->tf[l];
     float* hout = (l % 2 == 0) ? pl.ha : pl.hb;
     if ((rc = linear(h, t.w_in, m->precision, t.b_in.p, rows, 3 * d, d, 0, nullptr, nullptr, nullptr, pl.qkv, s))) return rc;
-    if ((rc = asw_attention(pl.qkv, B, L, d, c.num_head, pl.ctx, s))) return rc;
+    if ((rc = asw_attention_prec(pl.qkv, B, L, d, c.num_head, m->precision, pl.ctx, s))) return rc;
     if ((rc = linear(pl.ctx, t.w_out, m->precision, t.b_out.p, rows, d, d, 0, h, t.n1g.p, t.n1b.p, pl.x1, s))) return rc;
     if ((rc = linear(pl.x1, t.w1, m->precision, t.b1.p, rows, c.ffw_dim, d, 1, nullptr, nullptr, nullptr, pl.ff, s))) return rc;
     if ((rc = linear(pl.ff, t.w2, m->precision, t.b2.p, rows, d, c.ffw_dim, 0, pl.x1, t.n2g.p, t.n2b.p, hout, s))) return rc;

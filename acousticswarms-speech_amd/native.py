@@ -201,6 +201,7 @@ SIGNATURES = {
                            c_void_p]),
     "asw_gn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "asw_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "asw_attention_prec": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "asw_overlap_add_unnorm": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "asw_overlap_add_parts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,

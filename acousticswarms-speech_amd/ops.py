@@ -149,11 +149,12 @@ def add_layernorm(x, resid, gamma, beta, eps=1e-5):
     return out
 
 
-def attention(qkv, nhead):
+def attention(qkv, nhead, precision="f32"):
     B, L, d3 = qkv.shape
     d = d3 // 3
     ctx = torch.empty((B, L, d), dtype=torch.float32, device=qkv.device)
-    check(lib().asw_attention(ptr(_f32(qkv)), B, L, d, nhead, ptr(ctx), current_stream()))
+    check(lib().asw_attention_prec(ptr(_f32(qkv)), B, L, d, nhead, {"f32": 0, "f16x3": 1, "f16": 2}[precision], ptr(ctx),
+                                   current_stream()))
     return ctx
 
 

@@ -424,6 +424,10 @@ int asw_gn_finalize(const float* stats, int n_partials, int B, int T, int C, flo
  * (softmax(QK^T/sqrt(hd))V per head); nn.MultiheadAttention inside
  * nn.TransformerEncoderLayer (network.py:254). */
 int asw_attention(const float* qkv, int B, int L, int d, int nhead, float* ctx, void* stream);
+/* The same with the arithmetic of the two products chosen like asw_convgemm_args.precision: 0 = exact f32 MFMA
+ * (asw_attention), 1 / 2 = f16x3 split operands on the f16 MFMA (head_dim 128 and L <= 352; the softmax stays
+ * fp32; other shapes run as precision 0). */
+int asw_attention_prec(const float* qkv, int B, int L, int d, int nhead, int precision, float* ctx, void* stream);
 
 /* output_decoder ConvTranspose1d overlap-add + trim + un-normalise
  * (network.py:346-349,400-405; JointModel/network.py:96).

@@ -164,7 +164,10 @@ def test_linear_residual_layernorm(ops, d, f, L, B):
 
 @pytest.mark.parametrize("L,d,nhead,B", [(19, 128, 8, 3), (188, 1024, 8, 2), (300, 1024, 8, 1), (150, 1024, 8, 2),
                                          (192, 1024, 8, 1), (33, 1024, 8, 2), (47, 512, 4, 2), (563, 1024, 8, 1), (700, 1024, 8, 1)])
-def test_attention(ops, L, d, nhead, B):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_attention(ops, L, d, nhead, B, precision):
+    """f32: exact fp32 MFMA; f16x3: both products on the f16 MFMA with split operands (head_dim 128, L <= 352; other
+    shapes run the f32 kernels), the softmax in fp32 either way: same bar."""
     qkv = _rand(B, L, 3 * d, seed=28)
     hd = d // nhead
     q, k, v = qkv.split(d, dim=-1)
@@ -172,9 +175,9 @@ def test_attention(ops, L, d, nhead, B):
     k = k.view(B, L, nhead, hd).transpose(1, 2)
     v = v.view(B, L, nhead, hd).transpose(1, 2)
     want = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1) @ v).transpose(1, 2).reshape(B, L, d)
-    out = ops.attention(qkv.cuda(), nhead)
+    out = ops.attention(qkv.cuda(), nhead, precision=precision)
     rel, mx = _relerr(out.cpu(), want)
-    _log(f"attention L={L} d={d}: rel={rel:.3e} max={mx:.3e}")
+    _log(f"attention {precision} L={L} d={d}: rel={rel:.3e} max={mx:.3e}")
     assert rel < 3e-6
 
 
