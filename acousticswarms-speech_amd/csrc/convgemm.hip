@@ -1382,6 +1382,8 @@ extern "C" int asw_debug_phase_cycles(unsigned long long* out4, int reset) {
 }
 #endif
 
+namespace asw { int try_downconv64(const asw_convgemm_args& a, hipStream_t s); }
+
 extern "C" int asw_f16x3_overflow_count(int reset, uint32_t* count) {
   ASW_CHECK_ARG(count != nullptr, "f16x3_overflow_count: null pointer");
   unsigned int v = 0;
@@ -1496,6 +1498,10 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
     }
   }
   ASW_CHECK_ARG(!a.glu_raw, "convgemm: GroupNorm + GLU on load belongs to a residual layer (LayerNorm + residual)");
+  {
+    const int rc = asw::try_downconv64(a, s);          // stride-2 convolutions of a 64-channel input (downconv.hip)
+    if (rc != 1) return rc;
+  }
   if (wide_tile(a.N)) {
     if (a.precision >= 1) {
       // f16x3 is bound by the bytes each CU can pull per cycle, so take the largest tile the

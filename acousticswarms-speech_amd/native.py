@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASW_LIB_PATH") or os.path.join(_HERE, "libasw_hip.so")   # env: A/B builds only
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["asw_common.cpp", "convgemm.hip", "resstack.hip", "prep_kernels.hip", "misc_kernels.hip", "attention_mfma.hip", "srp_kernels.hip",
+SOURCES = ["asw_common.cpp", "convgemm.hip", "resstack.hip", "downconv.hip", "prep_kernels.hip", "misc_kernels.hip", "attention_mfma.hip", "srp_kernels.hip",
            "search_host.cpp", "sep_kernels.hip", "spot_model.hip", "sep_model.hip"]
 HEADERS = ["asw_common.h", "model_common.h", "mfma_util.h"]
 OPS_PATH = os.path.join(_HERE, "libasw_torch_ops.so")      # TORCH_LIBRARY(asw, ...) adapters over the C ABI

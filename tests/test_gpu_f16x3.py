@@ -57,6 +57,37 @@ def test_residual_layer_f16x3(C, T, dil, frag):
     assert r < 2e-5
 
 
+@pytest.mark.parametrize("Cout,T,K", [(64, 1000, 7), (128, 601, 7), (64, 37, 7), (128, 4100, 5), (64, 258, 5)])
+def test_stride2_conv_of_64_channels_f16x3(Cout, T, K):
+    """EncoderBlock tail of the two full-rate levels -- gate * x -> Conv1d(stride 2) -> GroupNorm(2) -> GLU
+    (network.py:101-113) -- through the halo-staged stride-2 kernel (csrc/downconv.hip: even / odd row images,
+    transposed accumulators) in f16x3 arithmetic, against torch fp32 and against the generic GEMM (ASW_NO_DOWNCONV is
+    read once per process, so the generic path is reached here through the fragment-free call)."""
+    from acousticswarms_speech_amd import ops
+    B, Cin = 3, 64
+    x = _rand(B, Cin, T, seed=8)
+    w = _rand(2 * Cout, Cin, K, seed=9, scale=1.0 / math.sqrt(Cin * K))
+    b = _rand(2 * Cout, seed=10, scale=0.1)
+    gate = 0.5 + _rand(Cin, seed=11, scale=0.2)
+    gg, gb = 1 + _rand(2 * Cout, seed=12, scale=0.1), _rand(2 * Cout, seed=13, scale=0.1)
+    raw = F.conv1d(gate.view(1, -1, 1) * x, w, b, stride=2, padding=K // 2)
+    want = F.glu(F.group_norm(raw, 2, gg, gb, 1e-5), dim=1).transpose(1, 2)
+    To = raw.shape[-1]
+    wt = ops.pack_conv_weight(w * gate.view(1, -1, 1)).cuda()
+    xc = x.transpose(1, 2).contiguous().cuda()
+    r, st = ops.convgemm(xc, wt, To, 2 * Cout, Cin, taps=K, stride=2, pad=K // 2, bias=b.cuda(), stats_chan_mod=2 * Cout,
+                         precision="f16x3")
+    r0, st0 = ops.convgemm(xc, wt, To, 2 * Cout, Cin, taps=K, stride=2, pad=K // 2, bias=b.cuda(), stats_chan_mod=2 * Cout,
+                           precision="f16x3", use_fragments=False)
+    rel_raw, rel_gen = _rel(r.cpu(), raw.transpose(1, 2)), _rel(r.cpu(), r0.cpu())
+    out = ops.gn_glu(r, st, gg.cuda(), gb.cuda())
+    out0 = ops.gn_glu(r0, st0, gg.cuda(), gb.cuda())
+    rel = _rel(out.cpu(), want)
+    _log(f"f16x3 down 64->{Cout} K={K} T={T}: raw rel {rel_raw:.3e}, vs generic kernel {rel_gen:.3e}, glu rel {rel:.3e}, "
+         f"glu vs generic {_rel(out.cpu(), out0.cpu()):.3e}")
+    assert rel_raw < 2e-5 and rel < 2e-5 and rel_gen < 3e-6
+
+
 def test_wide_and_scaled_operands_f16x3():
     """Plain / stats tiles; operands far from unit scale (tiny weights, large activations,
     values beyond the fp16 range saturate instead of turning into inf/NaN)."""
