@@ -190,6 +190,7 @@ struct Plan {
   std::vector<float*> intra_out, inter_out;   // per bottleneck layer (kept apart so every tap stays readable)
   float *h, *g, *x1, *x2, *x3, *qkv, *ctx, *raw2, *u, *v2, *y, *f, *pos;
   float *Y, *D, *ywave;
+  const int32_t* counts = nullptr;            // host [NB]: speakers present per item (NULL: S everywhere), forward() only
 };
 
 // The one-launch mask path (asw_mask_path_f16x3) applies in f16x3 mode when the shapes fit its tiles.
@@ -362,6 +363,14 @@ int run_network(asw_sep* m, Plan& pl, const float* mean, const float* stdv, floa
   for (int l = 0; l < c.bottleneck_layers; ++l) {
     if ((rc = run_conformer(m, pl, m->conf[l], x, pl.intra_out[l], s))) return rc;
     m->taps["intra" + std::to_string(l)] = {pl.intra_out[l], (size_t)B * pl.L * pl.d};
+    if (pl.counts) {
+      // items with fewer speakers: batches_to_speakers (:250-268) re-inserts the missing ones as ZERO sequences, which
+      // take part in the inter-speaker attention below; whatever the Conformer made of those rows is discarded
+      for (int n = 0; n < pl.NB; ++n)
+        if (pl.counts[n] < pl.S)
+          ASW_HIP(hipMemsetAsync(pl.intra_out[l] + ((size_t)n * pl.S + pl.counts[n]) * pl.L * pl.d, 0,
+                                 (size_t)(pl.S - pl.counts[n]) * pl.L * pl.d * sizeof(float), s));
+    }
     if ((rc = run_inter(m, pl, m->inter[l], pl.intra_out[l], pl.inter_out[l], s))) return rc;
     m->taps["inter" + std::to_string(l)] = {pl.inter_out[l], (size_t)B * pl.L * pl.d};
     x = pl.inter_out[l];
@@ -678,8 +687,22 @@ extern "C" int asw_sep_infer(asw_sep* m, const float* mix, int M, int T, const i
 }
 
 extern "C" int asw_sep_forward(asw_sep* m, const float* mix_norm, int B, int S, int M, int t, float* out, void* stream) {
+  return asw_sep_forward_counts(m, mix_norm, B, S, M, t, nullptr, out, stream);
+}
+
+extern "C" int asw_sep_forward_counts(asw_sep* m, const float* mix_norm, int B, int S, int M, int t, const int32_t* counts,
+                                      float* out, void* stream) {
   int rc = check_ready(m);
   if (rc) return rc;
+  if (counts) {
+    int mx = 0;
+    for (int n = 0; n < B; ++n) {
+      ASW_CHECK_ARG(counts[n] >= 1 && counts[n] <= S, "sep_forward: item %d holds %d speakers of a %d-wide stack", n, counts[n], S);
+      mx = counts[n] > mx ? counts[n] : mx;
+    }
+    ASW_CHECK_ARG(B == 0 || mx == S, "sep_forward: the stack is %d speakers wide but the largest item holds %d "
+                                     "(the reference pads to the largest count, :250-268)", S, mx);
+  }
   ASW_CHECK_ARG(B >= 0 && S >= 1 && (long)B * S <= 64, "sep_forward: B=%d S=%d (at most 64 sequences per call)", B, S);
   if (B == 0) return ASW_OK;
   ASW_CHECK_ARG(mix_norm && out, "sep_forward: null pointer");
@@ -696,7 +719,17 @@ extern "C" int asw_sep_forward(asw_sep* m, const float* mix_norm, int B, int S, 
   for (int sp = 1; sp < S; ++sp)
     ASW_HIP(hipMemcpy2DAsync(pl.refn + (size_t)sp * pl.RL, (size_t)S * pl.RL * sizeof(float), pl.refn,
                              (size_t)S * pl.RL * sizeof(float), (size_t)pl.RL * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+  pl.counts = counts;
   if ((rc = run_network(m, pl, nullptr, nullptr, pl.ywave, s))) return rc;
+  if (counts) {
+    // a missing speaker has a zero mask, so its output is the bare output_decoder bias (:474-484)
+    uint32_t bits;
+    memcpy(&bits, &m->out_bias, sizeof bits);
+    for (int n = 0; n < B; ++n)
+      if (counts[n] < S)
+        ASW_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(pl.ywave + ((size_t)n * S + counts[n]) * t), (int)bits,
+                                  (size_t)(S - counts[n]) * t, s));
+  }
   // rows padded with zeros to max_speakers (:486-488)
   const int R = S > m->cfg.max_speakers ? S : m->cfg.max_speakers;
   ASW_HIP(hipMemsetAsync(out, 0, (size_t)B * R * t * sizeof(float), s));

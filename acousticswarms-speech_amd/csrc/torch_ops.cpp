@@ -277,6 +277,31 @@ Tensor sep_forward(int64_t model, const Tensor& mix_norm, int64_t n_speakers, in
   return out;
 }
 
+// Network.forward with a speaker count per item: mix [B, S*M, t] with S = max(counts)
+Tensor sep_forward_counts(int64_t model, const Tensor& mix_norm, at::IntArrayRef counts, int64_t n_mics, int64_t max_speakers) {
+  TORCH_CHECK(model != 0, "sep_forward_counts: null model handle");
+  need(mix_norm, "mix", at::kFloat, 3);
+  const int B = checked_int(mix_norm.size(0), "B"), t = checked_int(mix_norm.size(2), "t"), M = checked_int(n_mics, "M");
+  TORCH_CHECK((int64_t)counts.size() == B && B >= 1, "counts must hold one entry per batch item");
+  std::vector<int32_t> c(B);
+  int S = 0;
+  for (int b = 0; b < B; ++b) {
+    c[b] = checked_int(counts[b], "count");
+    S = c[b] > S ? c[b] : S;
+  }
+  TORCH_CHECK(S >= 1 && mix_norm.size(1) == (int64_t)S * M, "mix must be [B, max(counts)*M, t]");
+  asw_sep_config cfg;
+  check_status(asw_sep_get_config(reinterpret_cast<asw_sep*>(model), &cfg), "asw_sep_get_config");
+  TORCH_CHECK(cfg.n_mics == M && cfg.max_speakers == max_speakers, "sep_forward_counts: n_mics / max_speakers differ from the model's");
+  const int64_t R = S > cfg.max_speakers ? S : cfg.max_speakers;
+  Tensor out = at::empty({B, R, t}, mix_norm.options());
+  Launch l(mix_norm);
+  check_status(asw_sep_forward_counts(reinterpret_cast<asw_sep*>(model), mix_norm.data_ptr<float>(), B, S, M, t, c.data(),
+                                      out.data_ptr<float>(), l.stream),
+               "asw_sep_forward_counts");
+  return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(asw, m) {
@@ -295,6 +320,7 @@ TORCH_LIBRARY(asw, m) {
         "int step, int n_windows, int nfft, int hop, float tol) -> Tensor");
   m.def("sep_infer(int model, Tensor mix, Tensor offsets) -> Tensor");
   m.def("sep_forward(int model, Tensor mix, int n_speakers, int n_mics, int max_speakers) -> Tensor");
+  m.def("sep_forward_counts(int model, Tensor mix, int[] counts, int n_mics, int max_speakers) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(asw, CUDA, m) {
@@ -309,4 +335,5 @@ TORCH_LIBRARY_IMPL(asw, CUDA, m) {
   m.impl("srp_phat_map", &srp_phat_map);
   m.impl("sep_infer", &sep_infer);
   m.impl("sep_forward", &sep_forward);
+  m.impl("sep_forward_counts", &sep_forward_counts);
 }

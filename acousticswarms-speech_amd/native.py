@@ -172,6 +172,7 @@ SIGNATURES = {
     "asw_sep_set_precision": (c_int, [c_void_p, c_int]),
     "asw_sep_infer": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "asw_sep_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "asw_sep_forward_counts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asw_sep_get_config": (c_int, [c_void_p, POINTER(SepConfigC)]),
     "asw_sep_get_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]),
     "asw_joint_shift_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

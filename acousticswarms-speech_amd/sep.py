@@ -154,22 +154,27 @@ class SepModel:
 
     def forward(self, mix, num_speakers):
         """Network.forward (:418-490): mix [B, S*M, t] already normalised, num_speakers [B,1]
-        -> device tensor [B, max(S, max_speakers), t].  Every item must hold the same number of
-        speakers (the reference pads ragged items with zero sequences that take part in the
-        inter-speaker attention; that case is not provided here and raises)."""
+        -> device tensor [B, max(max(S), max_speakers), t].  Items may hold different numbers of speakers: like the
+        reference (speakers_to_batches / batches_to_speakers, :236-268) only the first num_speakers[b] blocks of M
+        channels of item b are read, a missing speaker takes part in the inter-speaker attention as a zero sequence,
+        its output row is the bare output_decoder bias, and the stack is as wide as the largest count."""
         import torch
         self._need()
         ns = np.asarray(torch.as_tensor(num_speakers).cpu()).reshape(-1).astype(np.int64)
         mix = torch.as_tensor(mix).to(self.device, dtype=torch.float32).contiguous()
         B, SM, t = mix.shape
-        if ns.shape[0] != B or np.any(ns != ns[0]):
-            raise RuntimeError("SepModel.forward needs the same speaker count for every batch item")
-        S = int(ns[0])
-        if S < 1 or SM != S * self.n_mics:
-            raise RuntimeError(f"mix has {SM} channels, expected num_speakers*n_mics = {S * self.n_mics}")
+        if ns.shape[0] != B or B < 1:
+            raise RuntimeError(f"num_speakers holds {ns.shape[0]} entries for {B} batch items")
+        S = int(ns.max())
+        if ns.min() < 1 or SM % self.n_mics != 0 or SM < S * self.n_mics:
+            raise RuntimeError(f"mix has {SM} channels, expected at least max(num_speakers)*n_mics = {S * self.n_mics}")
         if B * S > MAX_SEQUENCES:
             raise RuntimeError(f"{B * S} sequences in one call; the library takes at most {MAX_SEQUENCES}")
-        return native.torch_ops().sep_forward(self._h.value, mix, S, self.n_mics, self.max_n_speaker)
+        if np.all(ns == S) and SM == S * self.n_mics:
+            return native.torch_ops().sep_forward(self._h.value, mix, S, self.n_mics, self.max_n_speaker)
+        if SM != S * self.n_mics:
+            mix = mix[:, :S * self.n_mics].contiguous()       # blocks beyond the largest count are never read (:244)
+        return native.torch_ops().sep_forward_counts(self._h.value, mix, [int(v) for v in ns], self.n_mics, self.max_n_speaker)
 
     __call__ = forward
 

@@ -189,6 +189,12 @@ int asw_sep_infer(asw_sep* m, const float* mix, int M, int T, const int32_t* off
  * speakers: mix_norm [B][S*M][t] -> out [B][max(S, max_speakers)][t] (rows beyond S are zeros,
  * :486-488).  B*S <= 64. */
 int asw_sep_forward(asw_sep* m, const float* mix_norm, int B, int S, int M, int t, float* out, void* stream);
+/* Network.forward with DIFFERENT speaker counts per item (speakers_to_batches / batches_to_speakers, :236-268):
+ * mix_norm [B][S*M][t] with S = the largest count; counts host int32 [B], 1 <= counts[b] <= S (NULL: S everywhere).
+ * A missing speaker enters every inter-speaker layer as a zero sequence and leaves as the bare output_decoder bias; the
+ * channels of its block in mix_norm are ignored. */
+int asw_sep_forward_counts(asw_sep* m, const float* mix_norm, int B, int S, int M, int t, const int32_t* counts,
+                           float* out, void* stream);
 /* The hyper-parameters the handle was created with (a caller that sizes `out` of asw_sep_forward from
  * max_speakers must use the handle's value, not its own). */
 int asw_sep_get_config(const asw_sep* m, asw_sep_config* out);

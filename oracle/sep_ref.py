@@ -149,17 +149,36 @@ def inter_layer(x, sd, p, nhead):
     return F.layer_norm(x + h, (d,), _t(sd, p + ".norm2.weight"), _t(sd, p + ".norm2.bias"), 1e-5)
 
 
-def bottleneck(x, sd, cfg, taps=None):
-    """BottleNeck.forward (:296-321) for equal speaker counts: x [N, S, d, L]."""
+def _to_batches(x, counts):
+    """speakers_to_batches (:236-247): x [B, S, ...] -> the first counts[b] speakers of every item, stacked."""
+    return torch.cat([x[b, :c] for b, c in enumerate(counts)], 0)
+
+
+def _to_speakers(x, counts):
+    """batches_to_speakers (:250-268): stacked speakers -> [B, max(counts), ...], missing speakers zero."""
+    m, out, pos = max(counts), [], 0
+    for c in counts:
+        blk = x[pos:pos + c]
+        if c < m:
+            blk = torch.cat([blk, torch.zeros((m - c,) + tuple(blk.shape[1:]), dtype=blk.dtype)], 0)
+        out.append(blk.unsqueeze(0))
+        pos += c
+    return torch.cat(out, 0)
+
+
+def bottleneck(x, sd, cfg, taps=None, counts=None):
+    """BottleNeck.forward (:296-321): x [N, S, d, L]; counts[b] <= S speakers present per item (default: all)."""
     N, S, d, L = x.shape
+    counts = [S] * N if counts is None else list(counts)
     pe = rel_pos_table(L, d, _t(sd, "bottleneck.pe_single.inv_freq"))
     for l in range(cfg.bottleneck_layers):
         p = f"bottleneck.module_list.{l}"
-        h = x.reshape(N * S, d, L).transpose(1, 2)                      # speakers_to_batches + transpose (:303-305)
+        h = _to_batches(x, counts).transpose(1, 2)                      # speakers_to_batches + transpose (:303-305)
         h = conformer_layer(h, sd, p + ".intra", cfg, pe)
+        h = _to_speakers(h, counts)                                     # [N, S, L, d], missing speakers zero (:309)
         if taps is not None:
-            taps[f"intra{l}"] = h.reshape(N, S, L, d)
-        h = h.reshape(N, S, L, d).permute(0, 2, 1, 3).reshape(N * L, S, d)   # (:311-314): rows (n,t), sequence = speakers
+            taps[f"intra{l}"] = h
+        h = h.permute(0, 2, 1, 3).reshape(N * L, S, d)                  # (:311-314): rows (n,t), sequence = speakers
         h = inter_layer(h, sd, p + ".inter.layers.0", cfg.num_head)
         x = h.reshape(N, L, S, d).permute(0, 2, 3, 1)
         if taps is not None:
@@ -168,18 +187,21 @@ def bottleneck(x, sd, cfg, taps=None):
 
 
 # --------------------------------------------------------------------------------------------
-# Network.forward (:418-490), equal speaker count S for every batch item
+# Network.forward (:418-490)
 # --------------------------------------------------------------------------------------------
-def sep_forward(sd, cfg, mix: torch.Tensor, n_speakers: int, taps: dict = None) -> torch.Tensor:
-    """mix [B, S*M, t] (already normalised) -> [B, max(S, max_speakers), t]."""
+def sep_forward(sd, cfg, mix: torch.Tensor, n_speakers, taps: dict = None) -> torch.Tensor:
+    """mix [B, S*M, t] (already normalised) -> [B, max(S, max_speakers), t].  n_speakers: one count for every item,
+    or a sequence of per-item counts (then S = the largest; only the first counts[b] channel blocks of item b are read)."""
     with torch.no_grad():
         B, SM, t_in = mix.shape
-        S, M = n_speakers, cfg.n_mics
-        assert SM == S * M
+        M = cfg.n_mics
+        counts = [int(n_speakers)] * B if np.isscalar(n_speakers) else [int(v) for v in np.asarray(n_speakers).reshape(-1)]
+        S = max(counts)
+        assert len(counts) == B and SM % M == 0 and SM >= S * M and min(counts) >= 1
         T = cfg.padded_length(t_in)
         mix = F.pad(mix, (T - t_in, 0))
         ref = mix[:, 0:1]                                              # first channel of the stack (:430)
-        x = mix.reshape(B * S, M, T)
+        x = _to_batches(mix.reshape(B, SM // M, M, T), counts)         # (:441-442)
         x = F.conv1d(x, _t(sd, "preproc.weight"), _t(sd, "preproc.bias"))
         skips = [x]
         for i, s in enumerate(cfg.stride_list):
@@ -187,8 +209,8 @@ def sep_forward(sd, cfg, mix: torch.Tensor, n_speakers: int, taps: dict = None) 
             skips.append(x)
             if taps is not None:
                 taps[f"enc{i}"] = x
-        d, L = x.shape[1], x.shape[2]
-        x = bottleneck(x.reshape(B, S, d, L), sd, cfg, taps).reshape(B * S, d, L)
+        x = bottleneck(_to_speakers(x, counts), sd, cfg, taps, counts)  # (:451-455)
+        x = _to_batches(x, counts)                                     # (:458)
         if taps is not None:
             taps["bottleneck"] = x
         for i, (_ci, _co, s) in enumerate(cfg.dec_channels()):
@@ -199,7 +221,8 @@ def sep_forward(sd, cfg, mix: torch.Tensor, n_speakers: int, taps: dict = None) 
         y = F.relu(F.conv1d(ref, _t(sd, "reference_bypass.weight"), _t(sd, "reference_bypass.bias"), stride=ES, padding=EK // 2))
         mask = F.relu(F.conv1d(x, _t(sd, "mask_encoder.weight"), _t(sd, "mask_encoder.bias"), stride=ES, padding=EK // 2))
         E, Fr = mask.shape[1], mask.shape[2]
-        lat = (y.unsqueeze(1) * mask.reshape(B, S, E, Fr)).reshape(B * S, E, Fr)      # (:466-477)
+        mask = _to_speakers(mask, counts)                              # [B, S, E, Fr], a missing speaker's mask is zero (:470)
+        lat = (y.unsqueeze(1) * mask).reshape(B * S, E, Fr)            # (:466-477)
         out = F.conv_transpose1d(lat, _t(sd, "output_decoder.weight"), _t(sd, "output_decoder.bias"), stride=EK // 2)
         out = out.reshape(B, S, -1)[..., 9:-8]
         if S < cfg.max_speakers:

@@ -76,6 +76,22 @@ def g11a():
     _save("g11a_sep_forward_small", **out)
 
 
+def g11d():
+    """Network.forward with DIFFERENT speaker counts per batch item (3, 1 and 2 of a 3-wide stack, and 2 / 3):
+    speakers_to_batches / batches_to_speakers (:236-268) drop and re-insert the missing speakers, whose zero rows take
+    part in the inter-speaker attention of every bottleneck layer, and whose outputs are the bare output_decoder bias."""
+    from acousticswarms_speech_amd.config import SEP_SMALL
+    net = _ref_sep_network(SEP_SMALL, seed=31)
+    out = {}
+    for name, counts, t in (("a", [3, 1, 2], 2100), ("b", [2, 3], 2048)):
+        rng = np.random.default_rng(900 + t)
+        x = torch.from_numpy(rng.standard_normal((len(counts), 3 * 7, t)).astype(np.float32))
+        with torch.no_grad():
+            out[f"y_{name}"] = net(x, torch.tensor(counts).view(-1, 1)).numpy()
+        out[f"counts_{name}"] = np.array(counts, dtype=np.int64)
+    _save("g11d_sep_forward_ragged", **out)
+
+
 def g11b():
     """Network.infer_sample, SEP_SMALL, on a seeded scene: 2, 3 and 6 (> max_speakers) speakers,
     fractional offsets (rounded half-to-even by the reference) and offsets beyond the clip length."""
@@ -145,7 +161,7 @@ def g12():
     _save("g12_best_permutation", n_cases=np.array(24), **cases)
 
 
-ALL = {"g11a": g11a, "g11b": g11b, "g11c": g11c, "g12": g12}
+ALL = {"g11a": g11a, "g11b": g11b, "g11c": g11c, "g11d": g11d, "g12": g12}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

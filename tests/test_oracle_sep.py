@@ -34,6 +34,26 @@ def test_forward_small_matches_reference(golden):
         assert _snr(y, want) > 100, _snr(y, want)
 
 
+def test_forward_with_different_speaker_counts_matches_reference(golden):
+    """g11d: the reference's Network.forward with 3 / 1 / 2 and 2 / 3 speakers per item (speakers_to_batches /
+    batches_to_speakers, :236-268): a missing speaker is a zero sequence in every inter-speaker layer and leaves as
+    the bare output_decoder bias; rows beyond the largest count are zero."""
+    g = golden("g11d_sep_forward_ragged")
+    sd = make_sep_state_dict(SEP_SMALL, 31)
+    for name, t in (("a", 2100), ("b", 2048)):
+        counts = [int(c) for c in g[f"counts_{name}"]]
+        rng = np.random.default_rng(900 + t)
+        x = torch.from_numpy(rng.standard_normal((len(counts), 21, t)).astype(np.float32))
+        y = sep_ref.sep_forward(sd, SEP_SMALL, x, counts).numpy()
+        want = g[f"y_{name}"]
+        assert y.shape == want.shape == (len(counts), SEP_SMALL.max_speakers, t)
+        assert _snr(y, want) > 100, _snr(y, want)
+        bias = float(sd["output_decoder.bias"][0])
+        for b, c in enumerate(counts):
+            assert np.all(want[b, c:3] == np.float32(bias)) and np.all(y[b, c:3] == np.float32(bias))
+        assert np.all(y[:, 3:] == 0) and np.all(want[:, 3:] == 0)
+
+
 def test_infer_sample_small_matches_reference(golden):
     g = golden("g11b_sep_infer_small")
     sd = make_sep_state_dict(SEP_SMALL, 31)
