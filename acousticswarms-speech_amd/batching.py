@@ -8,7 +8,8 @@ run concurrently -- one host thread per mixture, each with its own view of the (
 geometry tables -- and every scoring request they make goes through a ``CandidateBatcher``: the
 requests of different mixtures are concatenated into one candidate stream with a per-candidate
 mixture index and evaluated by ONE ``asw_spot_shift_and_sep_multi`` launch sequence, as soon as a
-full internal batch is waiting or every live search is blocked on its request.  Each search sees
+full internal batch is waiting, the device would otherwise idle, or every live search is stopped
+(``CandidateBatcher``'s launch rule).  Each search sees
 its own slice of the result, so its decisions are those of the plain per-mixture loop.
 
 Only the spot network's workspace is shared between the searches, and only the batcher touches
@@ -25,30 +26,46 @@ from .spot import offsets_from_patches
 
 
 class _Request(object):
-    __slots__ = ("k", "offs", "key", "want_wave", "wave", "energy", "done", "error")
+    __slots__ = ("k", "offs", "key", "want_wave", "wave", "energy", "done", "error", "event")
 
     def __init__(self, k, offs, key, want_wave):
         self.k, self.offs, self.key, self.want_wave = k, offs, key, want_wave
-        self.wave = self.energy = self.error = None
+        self.wave = self.energy = self.error = self.event = None
         self.done = False
 
 
 class CandidateBatcher(object):
     """Merges the scoring requests of ``n_workers`` concurrent searches over ``mix_stack [K,M,T]``
-    (cuda float32) into multi-mixture launches of ``model`` (a SpotModel on that device)."""
+    (cuda float32) into multi-mixture launches of ``model`` (a SpotModel on that device).
 
-    def __init__(self, model, mix_stack, n_workers, target=None):
+    Launch rule (``_pump``): waiting requests of one kind go out together as soon as
+      * they fill an internal batch (``target`` candidates), or
+      * the device has no launch of ours in flight (it would idle: a part-filled batch now beats a full one later), or
+      * every live search is stopped -- waiting here or for the result of a launch in flight -- so nothing more can
+        arrive before the device drains; at most ``max_inflight`` launches are queued ahead this way.
+    A search leaves ``request`` when its launch has been ENQUEUED and waits for the launch's end event outside the
+    lock, so the host work it does next (subdivision, clustering, SRP-PHAT of its next mixture) overlaps the launches
+    the other searches queued meanwhile -- merging everything into one launch per round would run the searches in
+    lock-step and leave the device idle during every host phase.  ``gpu_busy`` replaces the event query (host tests;
+    a CPU stand-in model computes inside ``_launch``, so there it defaults to "busy": merge until all are stopped)."""
+
+    def __init__(self, model, mix_stack, n_workers, target=None, gpu_busy=None, max_inflight=2, poll_s=1e-3):
         self.model, self.mixes = model, mix_stack
         self.live = int(n_workers)
         self.target = int(target or model.batch_size)
         self.cv = threading.Condition()
-        self.pending = []
-        self.blocked = 0
+        self.pending = []                                    # requests not launched yet (one per stopped search at most)
+        self.awaiting = 0                                    # searches waiting for a launch in flight
+        self.inflight = []                                   # end events of launches not yet seen complete
+        self.max_inflight, self.poll_s = int(max_inflight), float(poll_s)
+        self._busy_hook = gpu_busy
         self.launches = 0
         self.candidates = 0
         self.sizes = []                                      # candidates per launch
         self.host_s = 0.0                                    # host time spent enqueueing the launches
         self.events = []                                     # (start, end) device events per launch (stats)
+        self.wait_pending_s = 0.0                            # summed over searches: waiting for a launch to go out,
+        self.wait_device_s = 0.0                             # ... and for its end event
 
     def proxy(self, k):
         return MixtureScorer(self, int(k))
@@ -56,13 +73,24 @@ class CandidateBatcher(object):
     # ---- called by the searches -------------------------------------------------------------
     def request(self, k, offs, strict, window, want_wave):
         req = _Request(k, offs, (int(strict), int(window)), bool(want_wave))
+        t0 = time.perf_counter()
         with self.cv:
             self.pending.append(req)
-            self.blocked += 1
             self._pump()
             while not req.done:
-                self.cv.wait()
-            self.blocked -= 1
+                self.cv.wait(self.poll_s)                     # a launch draining on the device changes the rule's answer
+                if not req.done:
+                    self._pump()
+        t1 = time.perf_counter()
+        try:
+            if req.event is not None:
+                req.event.synchronize()                      # outside the lock: the others keep queueing
+        finally:
+            with self.cv:
+                self.awaiting -= 1
+                self.wait_pending_s += t1 - t0
+                self.wait_device_s += time.perf_counter() - t1
+                self._pump()
         if req.error is not None:
             raise RuntimeError(f"batched scoring failed: {req.error}")
         return req.wave, req.energy
@@ -74,13 +102,24 @@ class CandidateBatcher(object):
             self._pump()
 
     # ---- internals (lock held) -----------------------------------------------------------
+    def _gpu_busy(self):
+        if self._busy_hook is not None:
+            return bool(self._busy_hook())
+        if self.mixes.device.type != "cuda":
+            return True
+        self.inflight = [e for e in self.inflight if not e.query()]
+        return len(self.inflight) > 0
+
     def _pump(self):
         while self.pending:
             key = self.pending[0].key                       # oldest request decides which kind goes first
             group = [r for r in self.pending if r.key == key]
             total = sum(len(r.offs) for r in group)
-            if total < self.target and self.blocked < self.live:
-                return                                      # somebody is still on the host: wait for more candidates
+            if total < self.target and self._gpu_busy():
+                if len(self.pending) + self.awaiting < self.live:
+                    return                                  # somebody is still on the host: wait for more candidates
+                if len(self.inflight) >= self.max_inflight:
+                    return                                  # enough queued ahead; the poll in request() comes back
             self.pending = [r for r in self.pending if r.key != key]
             self._launch(group, key)
             self.cv.notify_all()
@@ -88,6 +127,7 @@ class CandidateBatcher(object):
     def _launch(self, group, key):
         import torch
         from . import native
+        self.awaiting += len(group)
         try:
             dev = self.mixes.device
             offs = np.ascontiguousarray(np.concatenate([r.offs for r in group], axis=0))
@@ -105,19 +145,21 @@ class CandidateBatcher(object):
             wave, en = self.model.shift_and_sep_device_multi(self.mixes, off_d, idx_d, key[0], want_wave=want_wave,
                                                              want_energy=True, window=key[1])
             self.host_s += time.perf_counter() - t_host
-            if on_gpu:
-                e1.record()
-                self.events.append((e0, e1))
             self.sizes.append(len(offs))
             if want_wave and on_gpu:
                 native.torch_ops().center_rows_(wave)       # the stage loops compare mean-removed outputs (Mic_Array.py:291)
             elif want_wave:
                 wave -= wave.mean(dim=1, keepdim=True)
+            if on_gpu:
+                e1.record()
+                self.events.append((e0, e1))
+                self.inflight.append(e1)
             pos = 0
             for r in group:
                 n = len(r.offs)
                 r.wave = wave[pos:pos + n] if r.want_wave else None
                 r.energy = en[pos:pos + n]
+                r.event = e1 if on_gpu else None
                 pos += n
             self.launches += 1
             self.candidates += pos
@@ -218,7 +260,10 @@ def search_batched(joint_model, mixes, concurrent=4):
                       "powers": np.array([p[2] for p in patches]), "names": [p[3] for p in patches],
                       "spot_times": spot_times, "times": times}
 
+    worker_s = []
+
     def work():
+        t_begin = time.perf_counter()
         try:
             while not errors:
                 with todo_lock:
@@ -230,6 +275,7 @@ def search_batched(joint_model, mixes, concurrent=4):
             errors.append(exc)
         finally:
             batcher.worker_done()
+            worker_s.append(time.perf_counter() - t_begin)
 
     threads = [threading.Thread(target=work, name=f"asw-search-{w}") for w in range(n_workers)]
     for t in threads:
@@ -240,5 +286,7 @@ def search_batched(joint_model, mixes, concurrent=4):
         raise errors[0]
     torch.cuda.synchronize(dev)
     stats = {"launches": batcher.launches, "candidates": batcher.candidates, "launch_sizes": list(batcher.sizes),
-             "spot_gpu_s": sum(a.elapsed_time(b) for a, b in batcher.events) * 1e-3, "enqueue_host_s": batcher.host_s}
+             "spot_gpu_s": sum(a.elapsed_time(b) for a, b in batcher.events) * 1e-3, "enqueue_host_s": batcher.host_s,
+             "wait_pending_s": batcher.wait_pending_s, "wait_device_s": batcher.wait_device_s,
+             "worker_s": sum(worker_s), "workers": n_workers}
     return results, stats

@@ -965,13 +965,14 @@ __global__ __launch_bounds__(64 * WM * WN)
 __attribute__((amdgpu_waves_per_eu(C == 64 ? 4 : WM * WN == 8 ? 2 : (QD == 2 ? (C >= 512 || (C == 256 && BM == 128) ? 2 : (C == 128 ? ASW_RES128_WAVES : 3)) : (C == 64 && WM * WN == 4 ? 4 : 1)))))
 void resconv16_kernel(const asw_convgemm_args p) {
   static_assert(QD == 2 || QD == 4, "B prefetch depth in k-steps");
-  static_assert(!GLU || (C == 64 && PH == 1 && !POLY), "GroupNorm + GLU on load: contiguous C = 64 tiles only");
+  static_assert(!GLU || (PH == 1 && !POLY), "GroupNorm + GLU on load: contiguous tiles only");
   static_assert(WM * WN == 2 || WM * WN == 4 || WM * WN == 8, "2, 4 or 8 waves per workgroup");
   constexpr int NTHR = 64 * WM * WN, SROWS = NTHR / 16;   // staging: 16 threads per row
   constexpr int TM = BM / WM / 32, TN = C / WN / 32;
   constexpr int RS = 272;                    // bytes per staged row: 128 hi + 128 lo + 16 pad
   constexpr int NT = C / 32;                 // 32-column fragments across N
   constexpr int BMJ = BM / PH;
+  constexpr int SU = (GLU && C > 64) ? 4 : 8;   // staging rows per thread in flight
   static_assert(BMJ % 32 == 0, "an MFMA row tile must stay inside one phase");
 
   extern __shared__ __align__(16) float smem[];
@@ -989,7 +990,7 @@ void resconv16_kernel(const asw_convgemm_args p) {
   const int RJ = BMJ + (!POLY ? (taps - 1) * dil : taps - 1);      // image rows per phase
   const int R = PH * RJ;
   const int tapstep = !POLY ? dil : 1;
-  // GLU: the input row g is GLU(GroupNorm(raw row g)), raw = [T][value half 64 | gate half 64]
+  // GLU: the input row g is GLU(GroupNorm(raw row g)), raw = [T][value half C | gate half C]
   const __amdgpu_buffer_rsrc_t rX = GLU ? act_rsrc(p.glu_raw + (long)b * T * 2 * C, (long)T * 2 * C)
                                         : act_rsrc(p.A + (long)b * p.a_batch_stride, (long)T * C);
   const half8* __restrict__ Wh = reinterpret_cast<const half8*>(p.Wf_hi);
@@ -1016,10 +1017,6 @@ void resconv16_kernel(const asw_convgemm_args p) {
   float4 gga, gba, ggg, gbg;
   if (GLU) {
     gm0 = p.glu_mr[b * 4 + 0]; gr0 = p.glu_mr[b * 4 + 1]; gm1 = p.glu_mr[b * 4 + 2]; gr1 = p.glu_mr[b * 4 + 3];
-    gga = *reinterpret_cast<const float4*>(p.glu_gamma + sc4 * 4);
-    gba = *reinterpret_cast<const float4*>(p.glu_beta + sc4 * 4);
-    ggg = *reinterpret_cast<const float4*>(p.glu_gamma + C + sc4 * 4);
-    gbg = *reinterpret_cast<const float4*>(p.glu_beta + C + sc4 * 4);
   }
   ASW_PHASE_MARK(t_begin);
 #ifdef ASW_PHASE_TIMING
@@ -1027,14 +1024,21 @@ void resconv16_kernel(const asw_convgemm_args p) {
 #endif
   for (int cc = 0; cc < C / 64; ++cc) {
     ASW_PHASE_MARK(t_s0);
+    if (GLU) {
+      gga = *reinterpret_cast<const float4*>(p.glu_gamma + cc * 64 + sc4 * 4);
+      gba = *reinterpret_cast<const float4*>(p.glu_beta + cc * 64 + sc4 * 4);
+      ggg = *reinterpret_cast<const float4*>(p.glu_gamma + C + cc * 64 + sc4 * 4);
+      gbg = *reinterpret_cast<const float4*>(p.glu_beta + C + cc * 64 + sc4 * 4);
+    }
     __syncthreads();                                   // previous slice fully consumed
-    // ---- stage + split the image of this channel slice (8 rows per thread in flight)
-    for (int r0 = 0; r0 < R; r0 += SROWS * 8) {
-      float4 buf[8];
-      float4 gate[GLU ? 8 : 1];
-      bool okr[GLU ? 8 : 1];
+    // ---- stage + split the image of this channel slice (8 loads per thread in flight: 8 rows, or 4 rows of value + gate
+    // halves where the accumulators leave no room for more)
+    for (int r0 = 0; r0 < R; r0 += SROWS * SU) {
+      float4 buf[SU];
+      float4 gate[GLU ? SU : 1];
+      bool okr[GLU ? SU : 1];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int row = r0 + u * SROWS + srow;
         int g;
         bool ok = row < R;
@@ -1047,8 +1051,8 @@ void resconv16_kernel(const asw_convgemm_args p) {
         }
         ok = ok && g >= 0 && g < T;
         if (GLU) {
-          buf[u] = act_load4(rX, (long)g * 2 * C + sc4 * 4, ok);
-          gate[u] = act_load4(rX, (long)g * 2 * C + C + sc4 * 4, ok);
+          buf[u] = act_load4(rX, (long)g * 2 * C + cc * 64 + sc4 * 4, ok);
+          gate[u] = act_load4(rX, (long)g * 2 * C + C + cc * 64 + sc4 * 4, ok);
           okr[u] = ok;
         } else {
           buf[u] = act_load4(rX, (long)g * C + cc * 64 + sc4 * 4, ok);
@@ -1057,7 +1061,7 @@ void resconv16_kernel(const asw_convgemm_args p) {
       if (GLU) {
         // the arithmetic of gn_glu_kernel, expression for expression; rows outside the sequence stay zero
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < SU; ++u) {
           float4 o;
 #define ASW_GLU(f)                                                       \
   {                                                                      \
@@ -1067,10 +1071,15 @@ void resconv16_kernel(const asw_convgemm_args p) {
           ASW_GLU(x) ASW_GLU(y) ASW_GLU(z) ASW_GLU(w)
 #undef ASW_GLU
           buf[u] = o;
+          // the normalised rows of the tile's own output range go out once as well: the skip connection of an
+          // encoder block, and (C > 64, where the image holds one channel slice at a time) this layer's residual
+          const int g = m0 - pad + r0 + u * SROWS + srow;
+          if (p.glu_out && okr[u] && g >= m0 && g < m0 + BM)
+            *reinterpret_cast<float4*>(p.glu_out + ((long)b * T + g) * C + cc * 64 + sc4 * 4) = o;
         }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int row = r0 + u * SROWS + srow;
         if (row < R) {
           half4 hi, lo;
@@ -1222,7 +1231,12 @@ int launch_res(const asw_convgemm_args& a, hipStream_t s) {
   int nl = snprintf(nm, sizeof nm, "resconv16<%d,%d,%s%d%s%s>", BM, C, POLY ? "poly" : "ph", PH, QD == 2 ? ",q2" : "", GLU ? ",glu" : "");
   if (asw::prof_detail()) snprintf(nm + nl, sizeof nm - nl, "[B%d M%d N%d K%d d%d]", a.B, a.M_out, a.N, a.taps * a.Cin, a.dil);
   asw::ProfScope prof(s, nm, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, a);
+  asw_convgemm_args k = a;
+  // C > 64: the image holds one 64-channel slice at a time, so the residual (= the normalised input) is read back
+  // from glu_out: the rows a workgroup reads in its epilogue are the ones it stored while staging (same CU, after
+  // the barriers of the k-loop)
+  if (GLU && C > 64) k.resid = a.glu_out;
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, k);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }
@@ -1236,6 +1250,11 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
                      !a.mul && !a.stats && a.pad * 2 == (a.taps - 1) * a.dil &&
                      a.a_len == (int64_t)a.M_out * a.Cin && a.a_batch_stride == a.a_len;
   if (!shape) return 1;
+  if (a.glu_raw) {
+    ASW_CHECK_ARG(a.dil == 1 && a.glu_mr && a.glu_gamma && a.glu_beta,
+                  "convgemm: GroupNorm + GLU on load needs dilation 1 and the statistics / affine arrays");
+    ASW_CHECK_ARG(a.N == 64 || a.glu_out, "convgemm: GroupNorm + GLU on load at %d channels takes the residual from glu_out", a.N);
+  }
   // large dilation: polyphase row sets -- but only while every phase still fills a 32-row
   // MFMA tile; on short sequences (T/dil < 32, e.g. T = 752 at dil 49) most of each tile
   // would be empty (measured: 141 vs 243 TFLOP/s), so those stay contiguous
@@ -1271,22 +1290,22 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
     case 64:
       // at C = 64 even dilation 7 is better off as 7 single-phase tiles (halo 6 instead of 42 rows per
       // 128 outputs, image 36 instead of 46 KB -> 4 resident workgroups): 238 -> 257 TFLOP/s
-      if (a.glu_raw) {
-        ASW_CHECK_ARG(a.dil == 1 && a.glu_mr && a.glu_gamma && a.glu_beta,
-                      "convgemm: GroupNorm + GLU on load needs dilation 1 and the statistics / affine arrays");
-        return launch_res<128, 64, 2, 2, 1, 4, false, true>(a, s);
-      }
+      if (a.glu_raw) return launch_res<128, 64, 2, 2, 1, 4, false, true>(a, s);
       if (a.dil >= 7 && a.dil < 16 && rows_per_phase >= 96) return launch_res<128, 64, 2, 2, 1, 4, true>(a, s);
       if (!poly) return launch_res<128, 64, 2, 2, 1>(a, s);
       if (rows_per_phase >= 96) return launch_res<128, 64, 2, 2, 1, 4, true>(a, s);
       return rows_per_phase >= 48 ? launch_res<128, 64, 2, 2, 2>(a, s) : launch_res<128, 64, 2, 2, 4>(a, s);
     case 128:
+      if (a.glu_raw) return launch_res<128, 128, 2, 2, 1, 2, false, true>(a, s);
       if (!poly) return launch_res<128, 128, 2, 2, 1, 2>(a, s);
       return rows_per_phase >= 48 ? launch_res<128, 128, 2, 2, 2, 2>(a, s) : launch_res<128, 128, 2, 2, 4, 2>(a, s);
     case 256: {
       // 128-row tiles (wave tile 128 x 64: half the weight-fragment traffic per MFMA, two waves per SIMD
       // instead of three) once they still fill the chip twice over: 313 -> 335 TFLOP/s at T = 48 000,
       // batch 64 (same box).  The same step at C = 128 (256-row tiles) loses, 300 -> 292.
+      if (a.glu_raw)
+        return (long)asw::cdiv(a.M_out, 128) * a.B >= 512 ? launch_res<128, 256, 1, 4, 1, 2, false, true>(a, s)
+                                                          : launch_res<64, 256, 1, 4, 1, 2, false, true>(a, s);
       if (!poly && (long)asw::cdiv(a.M_out, 128) * a.B >= 512) return launch_res<128, 256, 1, 4, 1, 2>(a, s);
       // (polyphase, two phases of 64 rows: 302 -> 307)
       if (poly && rows_per_phase >= 48 && (long)asw::cdiv(a.M_out, 128) * a.B >= 512) return launch_res<128, 256, 1, 4, 2, 2>(a, s);
@@ -1295,6 +1314,7 @@ int try_resconv(const asw_convgemm_args& a, hipStream_t s) {
     case 512:
       // polyphase at C = 512 pays only for long phases: 45 rows per phase (T = 144 000) measured 243
       // TFLOP/s against 307 for the contiguous halo image on the same layer shape at T = 48 000
+      if (a.glu_raw) return launch_res<64, 512, 1, 4, 1, 2, false, true>(a, s);
       if (poly && a.M_out / a.dil >= 64) return launch_res<64, 512, 1, 4, 2>(a, s);
       return a.dil >= 16 ? launch_res<64, 512, 1, 4, 1>(a, s) : launch_res<64, 512, 1, 4, 1, 2>(a, s);
     default: return 1;
@@ -1354,7 +1374,8 @@ inline bool wide_tile(int N) { return N % 128 == 0; }
 // that leave a 256-row tile a quarter or more empty (the bottleneck-side convolutions: 188 rows at
 // T = 48 000, 563 at T = 144 000 -> 2 % instead of 27 % of the MFMAs on padding rows).
 inline int wide_tile_kind(int B, int M_out, int N, int K) {
-  if (M_out <= 128 || N % 256 != 0 || K < 256) return 0;
+  static const int min_k = getenv("ASW_WIDE_MIN_K") ? atoi(getenv("ASW_WIDE_MIN_K")) : 256;   // A/B measurements
+  if (M_out <= 128 || N % 256 != 0 || K < min_k) return 0;
   const long blocks = (long)asw::cdiv(M_out, 256) * (N / 256) * B;
   if (blocks < 512) return 0;
   const long pad256 = (long)asw::cdiv(M_out, 256) * 256, pad192 = (long)asw::cdiv(M_out, 192) * 192;

@@ -149,11 +149,15 @@ struct Arena {
 
 // Input of a residual stack given as the un-normalised output of the preceding (transposed) convolution:
 // the first layer applies GroupNorm + GLU while it stages its rows (asw_convgemm_args.glu_raw).
-struct GluSrc { const float* raw; const float* mr; const float* gamma; const float* beta; };
+struct GluSrc { const float* raw; const float* mr; const float* gamma; const float* beta; float* side_out = nullptr; };
 
-// f16x3, 64 channels, first layer of dilation 1 with fragment-order weights: the layer that can do it
+// f16 arithmetic, 64..512 channels, first layer of dilation 1 with fragment-order weights: the layers that can do it.
+// Above 64 channels the layer needs GluSrc.side_out (it reads its residual from there).  ASW_GLU_ON_LOAD_MAX_C=64
+// keeps the wider blocks on the separate asw_gn_glu pass (A/B measurements).
 inline bool glu_on_load_ok(const std::vector<ResLayer>& res, int prec, int ch) {
-  return prec >= 1 && ch == 64 && !res.empty() && res[0].dil == 1 && res[0].wt.fhi && res[0].wt.flo;
+  static const int max_c = getenv("ASW_GLU_ON_LOAD_MAX_C") ? atoi(getenv("ASW_GLU_ON_LOAD_MAX_C")) : 512;
+  return prec >= 1 && (ch == 64 || ch == 128 || ch == 256 || ch == 512) && ch <= max_c && !res.empty() &&
+         res[0].dil == 1 && res[0].wt.fhi && res[0].wt.flo;
 }
 
 // 64-channel stacks in f16x3 arithmetic run through asw_resstack64_f16x3 (resstack.hip): consecutive layers whose
@@ -194,7 +198,9 @@ inline int run_res(const std::vector<ResLayer>& res, int prec, int B, int T, int
         a.layer[i].Wf_hi = r.wt.fhi; a.layer[i].Wf_lo = r.wt.flo; a.layer[i].w_shift = r.wt.shift;
         a.layer[i].bias = r.bias.p; a.layer[i].ln_gamma = r.g.p; a.layer[i].ln_beta = r.b.p; a.layer[i].dil = r.dil;
       }
-      if (glu && j == 0) { a.glu_raw = glu->raw; a.glu_mr = glu->mr; a.glu_gamma = glu->gamma; a.glu_beta = glu->beta; }
+      if (glu && j == 0) {
+        a.glu_raw = glu->raw; a.glu_mr = glu->mr; a.glu_gamma = glu->gamma; a.glu_beta = glu->beta; a.glu_out = glu->side_out;
+      }
       int rc = asw_resstack64_f16x3(&a, s);
       if (rc) return rc;
       in = outb;
@@ -207,7 +213,9 @@ inline int run_res(const std::vector<ResLayer>& res, int prec, int B, int T, int
   for (size_t j = 0; j < res.size(); ++j) {
     asw_convgemm_args a = {};
     a.A = in; res[j].wt.bind(a, prec); a.bias = res[j].bias.p; a.resid = in;
-    if (glu && j == 0) { a.glu_raw = glu->raw; a.glu_mr = glu->mr; a.glu_gamma = glu->gamma; a.glu_beta = glu->beta; }
+    if (glu && j == 0) {
+      a.glu_raw = glu->raw; a.glu_mr = glu->mr; a.glu_gamma = glu->gamma; a.glu_beta = glu->beta; a.glu_out = glu->side_out;
+    }
     a.ln_gamma = res[j].g.p; a.ln_beta = res[j].b.p; a.out = outb;
     a.B = B; a.M_out = T; a.N = ch; a.Cin = ch; a.taps = K; a.stride = 1; a.dil = res[j].dil;
     a.pad = (res[j].dil * (K - 1) + 1) / 2;

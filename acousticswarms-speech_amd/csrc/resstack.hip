@@ -71,6 +71,7 @@ struct KArgs {
   const float* glu_mr;
   const float* glu_gamma;
   const float* glu_beta;
+  float* glu_out;                        // optional: the GroupNorm + GLU rows of this tile's own output range, fp32
   int B, T, taps, ntile, BM, img_rows;
   float eps;
   LayerDev L[MAXL];
@@ -230,6 +231,12 @@ void resstack64_kernel(const KArgs p) {
           ASW_GLU(x) ASW_GLU(y) ASW_GLU(z) ASW_GLU(w)
 #undef ASW_GLU
           buf[u] = o;
+          // the normalised tensor is also a skip connection: each tile writes the rows of its own output range once
+          if (p.glu_out && okr[u]) {
+            const int g = m0 - p.L[0].halo - pad0 + r0 + u * SROWS + srow;
+            if (g >= m0 && g < m0 + p.BM)
+              *reinterpret_cast<float4*>(p.glu_out + ((long)b * T + g) * C + sc4 * 4) = o;
+          }
         }
       }
 #pragma unroll
@@ -515,6 +522,7 @@ extern "C" int asw_resstack64_f16x3(const asw_resstack_args* args, void* stream)
   if (glu) ASW_CHECK_ARG(a.glu_mr && a.glu_gamma && a.glu_beta, "resstack: GroupNorm + GLU on load needs the statistics / affine arrays");
   KArgs k = {};
   k.x = a.x; k.out = a.out; k.glu_raw = a.glu_raw; k.glu_mr = a.glu_mr; k.glu_gamma = a.glu_gamma; k.glu_beta = a.glu_beta;
+  k.glu_out = glu ? a.glu_out : nullptr;
   k.B = a.B; k.T = a.T; k.taps = a.taps; k.eps = a.ln_eps;
   int halo = 0;
   for (int i = a.n_layers - 1; i >= 0; --i) {

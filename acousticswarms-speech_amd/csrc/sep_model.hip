@@ -186,7 +186,7 @@ struct Plan {
   std::vector<int> Tl;
   float *mean, *stdv, *refn;
   double* jscr;
-  std::vector<float*> X, Pb, Qb, raw_dn, raw_up, st_dn, st_up, mr_up;
+  std::vector<float*> X, Pb, Qb, raw_dn, raw_up, st_dn, st_up, mr_up, mr_dn;
   std::vector<float*> intra_out, inter_out;   // per bottleneck layer (kept apart so every tap stays readable)
   float *h, *g, *x1, *x2, *x3, *qkv, *ctx, *raw2, *u, *v2, *y, *f, *pos;
   float *Y, *D, *ywave;
@@ -216,7 +216,7 @@ void layout(const asw_sep* m, int NB, int S, int T, Arena& a, Plan& pl) {
   pl.refn = a.take<float>((size_t)BS * pl.RL);
   pl.X.resize(c.depth + 1); pl.Pb.resize(c.depth); pl.Qb.resize(c.depth);
   pl.raw_dn.resize(c.depth); pl.raw_up.resize(c.depth); pl.st_dn.resize(c.depth); pl.st_up.resize(c.depth);
-  pl.mr_up.resize(c.depth);
+  pl.mr_up.resize(c.depth); pl.mr_dn.resize(c.depth);
   for (int i = 0; i <= c.depth; ++i) {
     const int ch = i == 0 ? c.channels : m->enc_cout[i - 1];
     pl.X[i] = a.take<float>((size_t)BS * pl.Tl[i] * ch);
@@ -227,6 +227,7 @@ void layout(const asw_sep* m, int NB, int S, int T, Arena& a, Plan& pl) {
     pl.Qb[i] = a.take<float>(n);
     pl.raw_dn[i] = a.take<float>((size_t)BS * pl.Tl[i + 1] * 2 * m->enc_cout[i]);
     pl.st_dn[i] = a.take<float>((size_t)BS * 4 * asw_convgemm_stats_tiles(pl.Tl[i + 1], 2 * m->enc_cout[i]));
+    pl.mr_dn[i] = a.take<float>((size_t)BS * 4);
   }
   for (int j = 0; j < c.depth; ++j) {
     const int lvl = c.depth - j;
@@ -341,9 +342,13 @@ int run_network(asw_sep* m, Plan& pl, const float* mean, const float* stdv, floa
   m->taps.clear();
   int rc;
   // ---- encoder (:84-156)
+  GluSrc enc_src = {};
+  bool enc_glu = false;                       // as in spot_model.hip: block i normalises raw_dn[i-1] while it stages
   for (int i = 0; i < c.depth; ++i) {
     float* r = nullptr;
-    if ((rc = run_res(m->enc[i].res, m->precision, B, pl.Tl[i], m->enc_cin[i], K, pl.X[i], pl.Pb[i], pl.Qb[i], &r, s))) return rc;
+    if ((rc = run_res(m->enc[i].res, m->precision, B, pl.Tl[i], m->enc_cin[i], K, pl.X[i], pl.Pb[i], pl.Qb[i], &r, s,
+                      enc_glu ? &enc_src : nullptr)))
+      return rc;
     asw_convgemm_args a = {};
     a.A = r; m->enc[i].down_wt.bind(a, m->precision); a.bias = m->enc[i].bias.p; a.out = pl.raw_dn[i]; a.stats = pl.st_dn[i];
     a.B = B; a.M_out = pl.Tl[i + 1]; a.N = 2 * m->enc_cout[i]; a.Cin = m->enc_cin[i]; a.taps = K;
@@ -351,9 +356,16 @@ int run_network(asw_sep* m, Plan& pl, const float* mean, const float* stdv, floa
     a.a_row_stride = a.Cin; a.a_batch_stride = (int64_t)pl.Tl[i] * a.Cin; a.a_len = a.a_batch_stride;
     a.chan_mod = a.N;
     if ((rc = asw_convgemm_f32(&a, s))) return rc;
-    if ((rc = asw_gn_glu(pl.raw_dn[i], pl.st_dn[i], asw_convgemm_stats_tiles(a.M_out, a.N), m->enc[i].gn_g.p,
-                         m->enc[i].gn_b.p, B, pl.Tl[i + 1], m->enc_cout[i], 1e-5f, pl.X[i + 1], s)))
+    enc_glu = i + 1 < c.depth && glu_on_load_ok(m->enc[i + 1].res, m->precision, m->enc_cout[i]);
+    if (enc_glu) {
+      if ((rc = asw_gn_finalize(pl.st_dn[i], asw_convgemm_stats_tiles(a.M_out, a.N), B, pl.Tl[i + 1], m->enc_cout[i], 1e-5f,
+                                pl.mr_dn[i], s)))
+        return rc;
+      enc_src = {pl.raw_dn[i], pl.mr_dn[i], m->enc[i].gn_g.p, m->enc[i].gn_b.p, pl.X[i + 1]};
+    } else if ((rc = asw_gn_glu(pl.raw_dn[i], pl.st_dn[i], asw_convgemm_stats_tiles(a.M_out, a.N), m->enc[i].gn_g.p,
+                                m->enc[i].gn_b.p, B, pl.Tl[i + 1], m->enc_cout[i], 1e-5f, pl.X[i + 1], s))) {
       return rc;
+    }
     m->taps["enc" + std::to_string(i)] = {pl.X[i + 1], (size_t)B * pl.Tl[i + 1] * m->enc_cout[i]};
   }
   // ---- bottleneck (:296-321): [BS][L][d] is already the (B*S, T, F) layout of the Conformer and,
@@ -390,10 +402,9 @@ int run_network(asw_sep* m, Plan& pl, const float* mean, const float* stdv, floa
     float* g = pl.Qb[lvl - 1];
     float* r = nullptr;
     if (true && glu_on_load_ok(m->dec[j].res, m->precision, co)) {
-      // 64-channel blocks: GroupNorm + GLU happen while the first residual layer stages its rows -- the
-      // normalised tensor is neither written nor read back (P -> g -> P are the stack's own buffers)
+      // GroupNorm + GLU happen while the first residual layer stages its rows (spot_model.hip, same place)
       if ((rc = asw_gn_finalize(pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), B, To, co, 1e-5f, pl.mr_up[j], s))) return rc;
-      const GluSrc src = {pl.raw_up[j], pl.mr_up[j], m->dec[j].gn_g.p, m->dec[j].gn_b.p};
+      const GluSrc src = {pl.raw_up[j], pl.mr_up[j], m->dec[j].gn_g.p, m->dec[j].gn_b.p, co > 64 ? g : nullptr};
       if ((rc = run_res(m->dec[j].res, m->precision, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s, &src))) return rc;
     } else {
       if ((rc = asw_gn_glu(pl.raw_up[j], pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), m->dec[j].gn_g.p,

@@ -220,7 +220,7 @@ struct Plan {
   std::vector<int> Tl;                     // length at level 0..depth
   float *mean, *stdv, *refn;
   std::vector<float*> X, Pb, Qb;           // level tensors: X[i] input of enc block i (X[0]=preproc out)
-  std::vector<float*> raw_dn, raw_up, st_dn, st_up, mr_up;
+  std::vector<float*> raw_dn, raw_up, st_dn, st_up, mr_up, mr_dn;
   float *qkv, *ctx, *x1, *ff, *ha, *hb, *Y, *D, *ywave;
   double *escr;
 };
@@ -239,7 +239,7 @@ void layout(const asw_spot* m, int B, int T, Arena& a, Plan& pl) {
   pl.refn = a.take<float>((size_t)B * pl.RL);
   pl.X.resize(c.depth + 1); pl.Pb.resize(c.depth); pl.Qb.resize(c.depth);
   pl.raw_dn.resize(c.depth); pl.raw_up.resize(c.depth); pl.st_dn.resize(c.depth); pl.st_up.resize(c.depth);
-  pl.mr_up.resize(c.depth);
+  pl.mr_up.resize(c.depth); pl.mr_dn.resize(c.depth);
   for (int i = 0; i <= c.depth; ++i) {
     const int ch = i == 0 ? c.channels : m->enc_cout[i - 1];
     pl.X[i] = a.take<float>((size_t)B * pl.Tl[i] * ch);
@@ -250,6 +250,7 @@ void layout(const asw_spot* m, int B, int T, Arena& a, Plan& pl) {
     pl.Qb[i] = a.take<float>(n);
     pl.raw_dn[i] = a.take<float>((size_t)B * pl.Tl[i + 1] * 2 * m->enc_cout[i]);
     pl.st_dn[i] = a.take<float>((size_t)B * 4 * asw_convgemm_stats_tiles(pl.Tl[i + 1], 2 * m->enc_cout[i]));
+    pl.mr_dn[i] = a.take<float>((size_t)B * 4);
   }
   for (int j = 0; j < c.depth; ++j) {
     const int lvl = c.depth - j;            // input level of decoder block j
@@ -297,9 +298,13 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
   m->taps["preproc"] = {pl.X[0], (size_t)B * pl.Tl[0] * c.channels};
   int rc;
   // ---- encoder (network.py:98-113,146-156)
+  GluSrc enc_src = {};
+  bool enc_glu = false;                       // X[i] is still un-normalised in raw_dn[i-1]: block i applies GroupNorm + GLU
   for (int i = 0; i < c.depth; ++i) {
     float* r = nullptr;
-    if ((rc = run_res(m->enc[i].res, m->precision, B, pl.Tl[i], m->enc_cin[i], K, pl.X[i], pl.Pb[i], pl.Qb[i], &r, s))) return rc;
+    if ((rc = run_res(m->enc[i].res, m->precision, B, pl.Tl[i], m->enc_cin[i], K, pl.X[i], pl.Pb[i], pl.Qb[i], &r, s,
+                      enc_glu ? &enc_src : nullptr)))
+      return rc;
     asw_convgemm_args a = {};
     a.A = r; gs->down_wt[i]->bind(a, m->precision); a.bias = m->enc[i].bias.p; a.out = pl.raw_dn[i]; a.stats = pl.st_dn[i];
     a.B = B; a.M_out = pl.Tl[i + 1]; a.N = 2 * m->enc_cout[i]; a.Cin = m->enc_cin[i]; a.taps = K;
@@ -307,9 +312,18 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
     a.a_row_stride = a.Cin; a.a_batch_stride = (int64_t)pl.Tl[i] * a.Cin; a.a_len = a.a_batch_stride;
     a.chan_mod = a.N;
     if ((rc = asw_convgemm_f32(&a, s))) return rc;
-    if ((rc = asw_gn_glu(pl.raw_dn[i], pl.st_dn[i], asw_convgemm_stats_tiles(a.M_out, a.N), m->enc[i].gn_g.p,
-                         m->enc[i].gn_b.p, B, pl.Tl[i + 1], m->enc_cout[i], 1e-5f, pl.X[i + 1], s)))
+    // the next block normalises while its first layer stages rows and writes X[i+1] (the skip connection the
+    // decoder reads) from the same registers: one pass over raw_dn less
+    enc_glu = m->fuse_mask && i + 1 < c.depth && glu_on_load_ok(m->enc[i + 1].res, m->precision, m->enc_cout[i]);
+    if (enc_glu) {
+      if ((rc = asw_gn_finalize(pl.st_dn[i], asw_convgemm_stats_tiles(a.M_out, a.N), B, pl.Tl[i + 1], m->enc_cout[i], 1e-5f,
+                                pl.mr_dn[i], s)))
+        return rc;
+      enc_src = {pl.raw_dn[i], pl.mr_dn[i], m->enc[i].gn_g.p, m->enc[i].gn_b.p, pl.X[i + 1]};
+    } else if ((rc = asw_gn_glu(pl.raw_dn[i], pl.st_dn[i], asw_convgemm_stats_tiles(a.M_out, a.N), m->enc[i].gn_g.p,
+                                m->enc[i].gn_b.p, B, pl.Tl[i + 1], m->enc_cout[i], 1e-5f, pl.X[i + 1], s))) {
       return rc;
+    }
     m->taps["enc" + std::to_string(i)] = {pl.X[i + 1], (size_t)B * pl.Tl[i + 1] * m->enc_cout[i]};
   }
   // ---- bottleneck (network.py:240-265): post-norm transformer layers, batch-first rows
@@ -341,10 +355,12 @@ int run_network(asw_spot* m, Plan& pl, GateSet* gs, const float* mean, const flo
     float* g = pl.Qb[lvl - 1];
     float* r = nullptr;
     if (m->fuse_mask && glu_on_load_ok(m->dec[j].res, m->precision, co)) {
-      // 64-channel blocks: GroupNorm + GLU happen while the first residual layer stages its rows -- the
-      // normalised tensor is neither written nor read back (P -> g -> P are the stack's own buffers)
+      // GroupNorm + GLU happen while the first residual layer stages its rows: at 64 channels the normalised
+      // tensor is neither written nor read back (P -> g -> P are the stack's own buffers), above that it is
+      // written once for the layer's residual instead of written and read twice
       if ((rc = asw_gn_finalize(pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), B, To, co, 1e-5f, pl.mr_up[j], s))) return rc;
-      const GluSrc src = {pl.raw_up[j], pl.mr_up[j], m->dec[j].gn_g.p, m->dec[j].gn_b.p};
+      // (g: free until the second layer writes it; the wide layers read their residual from there)
+      const GluSrc src = {pl.raw_up[j], pl.mr_up[j], m->dec[j].gn_g.p, m->dec[j].gn_b.p, co > 64 ? g : nullptr};
       if ((rc = run_res(m->dec[j].res, m->precision, B, To, co, K, g, pl.Pb[lvl - 1], g, &r, s, &src))) return rc;
     } else {
       if ((rc = asw_gn_glu(pl.raw_up[j], pl.st_up[j], asw_convgemm_stats_tiles(a.M_out, a.N), m->dec[j].gn_g.p,

@@ -122,7 +122,8 @@ class ConvGemmArgs(Structure):
                 ("a_batch_stride", c_int64), ("a_len", c_int64), ("chan_mod", c_int32), ("relu", c_int32),
                 ("ln_eps", c_float), ("precision", c_int32), ("w_shift", c_int32), ("Wt_hi", c_void_p),
                 ("Wt_lo", c_void_p), ("Wf_hi", c_void_p), ("Wf_lo", c_void_p), ("stats_stride", c_int32),
-                ("glu_raw", c_void_p), ("glu_mr", c_void_p), ("glu_gamma", c_void_p), ("glu_beta", c_void_p)]
+                ("glu_raw", c_void_p), ("glu_mr", c_void_p), ("glu_gamma", c_void_p), ("glu_beta", c_void_p),
+                ("glu_out", c_void_p)]
 
 
 class MaskPathArgs(Structure):
@@ -140,7 +141,8 @@ class ResLayerDesc(Structure):
 class ResStackArgs(Structure):
     _fields_ = [("x", c_void_p), ("out", c_void_p), ("B", c_int32), ("T", c_int32), ("C", c_int32), ("taps", c_int32),
                 ("n_layers", c_int32), ("precision", c_int32), ("ln_eps", c_float), ("layer", ResLayerDesc * 3),
-                ("glu_raw", c_void_p), ("glu_mr", c_void_p), ("glu_gamma", c_void_p), ("glu_beta", c_void_p)]
+                ("glu_raw", c_void_p), ("glu_mr", c_void_p), ("glu_gamma", c_void_p), ("glu_beta", c_void_p),
+                ("glu_out", c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/asw_hip.h

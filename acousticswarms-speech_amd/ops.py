@@ -24,7 +24,7 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, relu=False, resid=None, mul=None,
              ln=None, stats_chan_mod=0, A2=None, B=None, a_row_stride=None, a_batch_stride=None, a_len=None,
-             out=None, ln_eps=1e-5, precision="f32", use_fragments=True, glu=None):
+             out=None, ln_eps=1e-5, precision="f32", use_fragments=True, glu=None, glu_out=None):
     """out[b][r][n] per include/asw_hip.h:asw_convgemm_f32.  Returns (out, stats|None)."""
     _f32(A); _f32(Wt)
     if B is None:
@@ -54,6 +54,8 @@ def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, re
     a.chan_mod, a.relu, a.ln_eps = stats_chan_mod, int(relu), ln_eps
     if glu is not None:                      # (raw [B][M_out][2N], mr [B][4], gamma [2N], beta [2N]): GroupNorm + GLU on load
         a.glu_raw, a.glu_mr, a.glu_gamma, a.glu_beta = (_f32(t).data_ptr() for t in glu)
+        if glu_out is not None:
+            a.glu_out = _f32(glu_out).data_ptr()
     keep = None
     if precision in ("f16x3", "f16"):
         hi, lo, shift = split_weights_f16(Wt)
@@ -69,7 +71,7 @@ def convgemm(A, Wt, M_out, N, Cin, taps=1, stride=1, dil=1, pad=0, bias=None, re
     return out, stats
 
 
-def resstack(x, layers, taps=7, precision="f16x3", eps=1e-5, glu=None, out=None):
+def resstack(x, layers, taps=7, precision="f16x3", eps=1e-5, glu=None, out=None, glu_out=None):
     """A stack of 1..3 64-channel residual layers in one launch (include/asw_hip.h:asw_resstack64_f16x3).
     layers: [(Wt [64][taps*64], bias, gamma, beta, dil), ...]; x [B][T][64] or None with glu = (raw, mr, gamma, beta)."""
     src = x if glu is None else glu[0]
@@ -90,6 +92,8 @@ def resstack(x, layers, taps=7, precision="f16x3", eps=1e-5, glu=None, out=None)
         d.bias, d.ln_gamma, d.ln_beta = _f32(bias).data_ptr(), _f32(gamma).data_ptr(), _f32(beta).data_ptr()
     if glu is not None:
         a.glu_raw, a.glu_mr, a.glu_gamma, a.glu_beta = (_f32(t).data_ptr() for t in glu)
+        if glu_out is not None:
+            a.glu_out = _f32(glu_out).data_ptr()
     check(lib().asw_resstack64_f16x3(byref(a), current_stream()))
     torch.cuda.current_stream().synchronize()
     return out

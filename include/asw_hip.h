@@ -319,16 +319,20 @@ typedef struct asw_convgemm_args {
   const void* Wf_hi;
   const void* Wf_lo;
   int32_t stats_stride;   /* set by the library: partial-statistics slots per batch item */
-  /* Optional (precision 1, the halo-staged residual layer with C_in == N == 64, dilation 1, i.e. the first
-   * layer of the decoder blocks' residual stacks): take the layer's input -- and residual -- from the
+  /* Optional (precision >= 1, the halo-staged residual layer with C_in == N in {64, 128, 256, 512}, dilation 1,
+   * i.e. the first layer of a block's residual stack): take the layer's input -- and residual -- from the
    * un-normalised output of the preceding transposed convolution instead of A, applying GroupNorm(2) + GLU
    * while the rows are staged (the arithmetic of asw_gn_glu, bit for bit), so that tensor is neither written
-   * nor read back.  glu_raw [B][M_out][128] (value half | gate half of every output row), glu_mr [B][4] =
-   * (mean0, rstd0, mean1, rstd1) from asw_gn_finalize, glu_gamma / glu_beta [128].  A is ignored. */
+   * nor read back.  glu_raw [B][M_out][2N] (value half | gate half of every output row), glu_mr [B][4] =
+   * (mean0, rstd0, mean1, rstd1) from asw_gn_finalize, glu_gamma / glu_beta [2N].  A is ignored. */
   const float* glu_raw;
   const float* glu_mr;
   const float* glu_gamma;
   const float* glu_beta;
+  /* [B][M_out][N]: receives GLU(GroupNorm(glu_raw)), the layer's input, as a tensor (an encoder block's skip
+   * connection).  Optional at N == 64; required at N = 128 / 256 / 512, where the layer also reads its residual
+   * from it (each workgroup the rows it wrote itself). */
+  float* glu_out;
 } asw_convgemm_args;
 /* Host helper: fp32 Wt[N][K] -> fragment-major fp16 hi/lo [K/16][N/32][64 lanes][8]:
  * lane l of fragment (ks, nt) holds Wt[nt*32 + (l&31)][ks*16 + 8*(l>>5) + j], j < 8, i.e.
@@ -400,6 +404,8 @@ typedef struct asw_resstack_args {
   const float* glu_mr;
   const float* glu_gamma;
   const float* glu_beta;
+  float* glu_out;         /* optional with glu_raw: [B][T][64], receives GLU(GroupNorm(glu_raw)) -- the stack's input --
+                             for a caller that needs it as a tensor as well (the encoder's skip connection) */
 } asw_resstack_args;
 int asw_resstack64_f16x3(const asw_resstack_args* args, void* stream);
 /* Host helper: split n fp32 weights into the fp16 hi/lo pair used by precision 1 with the

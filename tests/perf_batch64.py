@@ -44,6 +44,8 @@ def main(n_mix=64, T=48000, concurrent=4, batch=256):
                       "spot_candidates": int(cands), "candidates_per_s_in_search": round(cands / dt, 1),
                       "batcher": (lambda st: None if st is None else {
                           "launches": st["launches"], "spot_gpu_s": round(st["spot_gpu_s"], 2), "enqueue_host_s": round(st["enqueue_host_s"], 2),
+                          "wait_pending_s": round(st["wait_pending_s"], 2), "wait_device_s": round(st["wait_device_s"], 2),
+                          "worker_s": round(st["worker_s"], 2),
                           "median_launch": int(np.median(st["launch_sizes"])), "max_launch": int(max(st["launch_sizes"]))})(
                           getattr(localize_batch, "last_stats", None) if concurrent > 1 else None),
                       "talkers_found_mean": round(float(np.mean([len(r["names"]) for r in out])), 2),

@@ -138,3 +138,32 @@ def test_launch_error_reaches_every_waiting_search():
     [t.start() for t in ts]
     [t.join(timeout=10) for t in ts]
     assert len(errs) == 2 and all("device fault" in e for e in errs)
+
+
+def test_idle_device_gets_a_part_filled_launch_and_a_busy_one_makes_requests_wait():
+    """the launch rule's device side, driven through the gpu_busy hook: an idle device takes whatever is waiting at
+    once; while it is busy a lone request waits (here: until the poll sees the device idle again)."""
+    mixes = torch.zeros(3, 2, 4)
+    mixes[:, 0, 0] = torch.arange(1, 4)
+    model = _FakeModel()
+    busy = {"v": False}
+    batcher = CandidateBatcher(model, mixes, n_workers=3, target=100, gpu_busy=lambda: busy["v"], poll_s=1e-3)
+    offs = np.ones((2, 1), dtype=np.int32)
+    _w, en = batcher.request(0, offs, 0, 12000, False)          # workers 1, 2 never asked, the batch is far from full
+    np.testing.assert_array_equal(en.numpy(), _expected(0, offs, 0))
+    assert batcher.launches == 1 and batcher.awaiting == 0
+    busy["v"] = True
+    got = {}
+
+    def requester():
+        _w, e = batcher.request(1, offs, 0, 12000, False)
+        got["en"] = e.numpy()
+
+    t = threading.Thread(target=requester)
+    t.start()
+    time.sleep(0.05)
+    assert t.is_alive() and batcher.launches == 1               # busy device, others still on the host: it waits
+    busy["v"] = False                                           # the launch in flight drained
+    t.join(timeout=10)
+    assert not t.is_alive() and batcher.launches == 2
+    np.testing.assert_array_equal(got["en"], _expected(1, offs, 0))

@@ -178,6 +178,36 @@ def test_groupnorm_glu_on_load_is_bit_identical(T):
                      **dict(kw, pad=21))
 
 
+@pytest.mark.parametrize("C,T", [(64, 333), (128, 1000), (128, 77), (256, 300), (256, 3008), (512, 200), (512, 64)])
+def test_groupnorm_glu_on_load_wide_blocks_and_side_output(C, T):
+    """The same at 128 / 256 / 512 channels (the image holds one 64-channel slice at a time): the layer also writes
+    the normalised rows of its own output range to glu_out -- the encoder's skip connection -- and reads its residual
+    back from there.  Output and side tensor equal asw_gn_glu + the plain layer bit for bit."""
+    from acousticswarms_speech_amd import ops
+    B, K = (5 if T == 3008 else 2), 7                 # 256 channels: the 128-row tile needs >= 512 workgroups, else 64 rows
+    raw = (_rand(B, T, 2 * C, seed=170) * 1.3 - 0.2).cuda()
+    gamma, beta = (1 + 0.2 * _rand(2 * C, seed=171)).cuda(), (0.1 * _rand(2 * C, seed=172)).cuda()
+    w = _rand(C, C, K, seed=173, scale=1 / math.sqrt(C * K))
+    bias, lg, lb = _rand(C, seed=174, scale=0.1).cuda(), (1 + 0.1 * _rand(C, seed=175)).cuda(), (0.1 * _rand(C, seed=176)).cuda()
+    r = raw.double()
+    stats = torch.stack([r[..., :C].sum((1, 2)), (r[..., :C] ** 2).sum((1, 2)), r[..., C:].sum((1, 2)),
+                         (r[..., C:] ** 2).sum((1, 2))], dim=1).float().view(B, 1, 4).contiguous()
+    g = ops.gn_glu(raw, stats, gamma, beta)
+    Wt = ops.pack_conv_weight(w).cuda()
+    kw = dict(taps=K, pad=3, bias=bias, relu=True, ln=(lg, lb), precision="f16x3")
+    want, _ = ops.convgemm(g, Wt, T, C, C, resid=g, **kw)
+    mr = ops.gn_finalize(stats, T, C)
+    side = torch.full((B, T, C), float("nan"), device="cuda")
+    got, _ = ops.convgemm(raw, Wt, T, C, C, resid=raw, a_batch_stride=T * C, a_len=T * C, B=B,
+                          glu=(raw, mr, gamma, beta), glu_out=side, **kw)
+    _log(f"glu-on-load C={C} T={T}: out max diff {float((got - want).abs().max()):.2e}, side max diff {float((side - g).abs().max()):.2e}")
+    assert torch.equal(side, g)
+    assert torch.equal(got, want)
+    if C > 64:
+        with pytest.raises(RuntimeError):            # no place for the residual: refused
+            ops.convgemm(raw, Wt, T, C, C, resid=raw, a_batch_stride=T * C, a_len=T * C, B=B, glu=(raw, mr, gamma, beta), **kw)
+
+
 def test_single_pass_f16_mode_vs_reference_golden(golden):
     """precision="f16": one MFMA per product on round-to-nearest fp16 halves (the reference's own half-precision
     switch, `use_fp16`, is bf16 autocast and hard-wired off).  An OPTIONAL mode, never the headline: against the

@@ -124,6 +124,20 @@ def test_resstack_groupnorm_glu_on_load():
     b = ops.resstack(None, layers, taps=7, glu=(raw, mr, gg, gb))
     _log(f"resstack glu-on-load: max abs diff {float((a - b).abs().max()):.3e}")
     assert torch.equal(a, b)
+    # the encoder's form: the normalised rows are also written out once (the skip connection), each by the tile that owns them
+    for dils, Tn in (((1, 7), T), ((1,), 701), ((1, 7), 48128)):
+        rawn = _rand(B, Tn, 2 * C, seed=17).cuda()
+        stn = torch.zeros(B, 1, 4, device="cuda")
+        stn[:, 0, 0] = rawn[:, :, :C].sum((1, 2)); stn[:, 0, 1] = (rawn[:, :, :C] ** 2).sum((1, 2))
+        stn[:, 0, 2] = rawn[:, :, C:].sum((1, 2)); stn[:, 0, 3] = (rawn[:, :, C:] ** 2).sum((1, 2))
+        xn, mrn = ops.gn_glu(rawn, stn, gg, gb), ops.gn_finalize(stn, Tn, C)
+        ly = _dev_layers(ops, _layers(dils, 7, seed=71))
+        side = torch.full((B, Tn, C), float("nan"), device="cuda")
+        c = ops.resstack(None, ly, taps=7, glu=(rawn, mrn, gg, gb), glu_out=side)
+        assert torch.equal(c, ops.resstack(xn, ly, taps=7))
+        d = float((side - xn).abs().max())
+        _log(f"resstack glu side output dils={dils} T={Tn}: max abs diff to asw_gn_glu {d:.3e}, bit-equal {torch.equal(side, xn)}")
+        assert torch.isfinite(side).all() and d <= 1e-6
 
 
 def test_resstack_full_size_properties():
