@@ -56,7 +56,11 @@ __device__ __forceinline__ float gn_glu_value(float a, float g, float m0, float 
                                               float gg, float bg) {
   const float av = __fmaf_rn(__fmul_rn(__fsub_rn(a, m0), r0), ga, ba);
   const float gv = __fmaf_rn(__fmul_rn(__fsub_rn(g, m1), r1), gg, bg);
-  return __fdiv_rn(av, __fadd_rn(1.0f, expf(-gv)));
+  // sigmoid on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each, about 3e-7 overall): the IEEE expf +
+  // division sequence is some 35 VALU instructions per element, and in the layers that normalise while they stage
+  // their rows (resstack.hip, resconv16) that was 10 k of a workgroup's 70 k cycles with the matrix pipe idle
+  const float e = __builtin_amdgcn_exp2f(__fmul_rn(gv, -1.4426950408889634f));
+  return __fmul_rn(av, __builtin_amdgcn_rcpf(__fadd_rn(1.0f, e)));
 }
 #endif
 
