@@ -38,18 +38,21 @@ class CandidateBatcher(object):
     """Merges the scoring requests of ``n_workers`` concurrent searches over ``mix_stack [K,M,T]``
     (cuda float32) into multi-mixture launches of ``model`` (a SpotModel on that device).
 
-    Launch rule (``_pump``): waiting requests of one kind go out together as soon as
+    Launch rule (``_pump``): the waiting requests of one kind go out together as soon as
       * they fill an internal batch (``target`` candidates), or
-      * the device has no launch of ours in flight (it would idle: a part-filled batch now beats a full one later), or
-      * every live search is stopped -- waiting here or for the result of a launch in flight -- so nothing more can
-        arrive before the device drains; at most ``max_inflight`` launches are queued ahead this way.
+      * fewer than ``max_inflight`` (2) launches of this batcher are queued on the device: the device always has its
+        next launch behind the running one, so it never waits for a host round trip (poll, enqueue: 1-2 ms per
+        launch), and whatever arrives while two are queued accumulates and is merged.
     A search leaves ``request`` when its launch has been ENQUEUED and waits for the launch's end event outside the
     lock, so the host work it does next (subdivision, clustering, SRP-PHAT of its next mixture) overlaps the launches
-    the other searches queued meanwhile -- merging everything into one launch per round would run the searches in
-    lock-step and leave the device idle during every host phase.  ``gpu_busy`` replaces the event query (host tests;
-    a CPU stand-in model computes inside ``_launch``, so there it defaults to "busy": merge until all are stopped)."""
+    the other searches queued meanwhile.  (Two earlier rules, both measured on the 64-mixture run: "launch when a
+    batch is full or every search is blocked" runs the searches in lock-step -- the device idles during every host
+    phase; "launch when the device is idle, wait otherwise" never merges and leaves a bubble at every launch
+    boundary, because half of the searches are always outside the batcher in their own small kernels and read-backs.)
+    ``inflight`` replaces the event query (host tests); a CPU stand-in model computes inside ``_launch``, nothing is
+    ever in flight there and the rule falls back to: merge until every live search is waiting."""
 
-    def __init__(self, model, mix_stack, n_workers, target=None, gpu_busy=None, max_inflight=2, poll_s=1e-3):
+    def __init__(self, model, mix_stack, n_workers, target=None, inflight=None, max_inflight=2, poll_s=1e-3):
         self.model, self.mixes = model, mix_stack
         self.live = int(n_workers)
         self.target = int(target or model.batch_size)
@@ -58,7 +61,18 @@ class CandidateBatcher(object):
         self.awaiting = 0                                    # searches waiting for a launch in flight
         self.inflight = []                                   # end events of launches not yet seen complete
         self.max_inflight, self.poll_s = int(max_inflight), float(poll_s)
-        self._busy_hook = gpu_busy
+        self._inflight_hook = inflight
+        # The launches run on a stream of their own.  On the searches' (default) stream every event a search records
+        # and every small read-back it waits for would queue behind whole launches of the OTHER searches (40-100 ms
+        # each): the searches then spend most of their time blocked outside the batcher, are never "all stopped",
+        # and nothing gets merged or queued ahead (measured: 97 ms per request outside the batcher against 4 ms in
+        # the plain loop).
+        self.stream = None
+        if mix_stack.device.type == "cuda":
+            import torch
+            self.stream = torch.cuda.Stream(device=mix_stack.device)
+        self.requests = 0
+        self.reasons = {}                                    # launches by the rule that sent them (stats)
         self.launches = 0
         self.candidates = 0
         self.sizes = []                                      # candidates per launch
@@ -76,6 +90,7 @@ class CandidateBatcher(object):
         t0 = time.perf_counter()
         with self.cv:
             self.pending.append(req)
+            self.requests += 1
             self._pump()
             while not req.done:
                 self.cv.wait(self.poll_s)                     # a launch draining on the device changes the rule's answer
@@ -85,6 +100,12 @@ class CandidateBatcher(object):
         try:
             if req.event is not None:
                 req.event.synchronize()                      # outside the lock: the others keep queueing
+                if self.stream is not None:
+                    import torch
+                    cur = torch.cuda.current_stream(self.mixes.device)
+                    for t in (req.wave, req.energy):         # allocated on the launch stream, consumed on the search's
+                        if t is not None:
+                            t.record_stream(cur)
         finally:
             with self.cv:
                 self.awaiting -= 1
@@ -102,72 +123,87 @@ class CandidateBatcher(object):
             self._pump()
 
     # ---- internals (lock held) -----------------------------------------------------------
-    def _gpu_busy(self):
-        if self._busy_hook is not None:
-            return bool(self._busy_hook())
+    def _inflight(self):
+        """launches of this batcher the device has not finished yet; None when that cannot be asked (CPU stand-in)"""
+        if self._inflight_hook is not None:
+            return int(self._inflight_hook())
         if self.mixes.device.type != "cuda":
-            return True
+            return None
         self.inflight = [e for e in self.inflight if not e.query()]
-        return len(self.inflight) > 0
+        return len(self.inflight)
 
     def _pump(self):
         while self.pending:
             key = self.pending[0].key                       # oldest request decides which kind goes first
             group = [r for r in self.pending if r.key == key]
             total = sum(len(r.offs) for r in group)
-            if total < self.target and self._gpu_busy():
-                if len(self.pending) + self.awaiting < self.live:
-                    return                                  # somebody is still on the host: wait for more candidates
-                if len(self.inflight) >= self.max_inflight:
+            why = "full"
+            if total < self.target:
+                n = self._inflight()
+                if n is None:
+                    if len(self.pending) < self.live:
+                        return                              # somebody is still on the host: wait for more candidates
+                    why = "all_waiting"
+                elif n >= self.max_inflight:
                     return                                  # enough queued ahead; the poll in request() comes back
+                else:
+                    why = "queue_ahead"
+            self.reasons[why] = self.reasons.get(why, 0) + 1
             self.pending = [r for r in self.pending if r.key != key]
             self._launch(group, key)
             self.cv.notify_all()
 
     def _launch(self, group, key):
+        import contextlib
         import torch
-        from . import native
         self.awaiting += len(group)
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
         try:
-            dev = self.mixes.device
-            offs = np.ascontiguousarray(np.concatenate([r.offs for r in group], axis=0))
-            idx = np.concatenate([np.full(len(r.offs), r.k, dtype=np.int32) for r in group])
-            assert idx.min() >= 0 and idx.max() < self.mixes.shape[0]
-            on_gpu = dev.type == "cuda"                      # (a CPU stand-in model drives this class in the host tests)
-            off_d, idx_d = torch.from_numpy(offs), torch.from_numpy(idx)
-            if on_gpu:
-                off_d = off_d.pin_memory().to(dev, non_blocking=True)
-                idx_d = idx_d.pin_memory().to(dev, non_blocking=True)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            want_wave = any(r.want_wave for r in group)
-            t_host = time.perf_counter()
-            wave, en = self.model.shift_and_sep_device_multi(self.mixes, off_d, idx_d, key[0], want_wave=want_wave,
-                                                             want_energy=True, window=key[1])
-            self.host_s += time.perf_counter() - t_host
-            self.sizes.append(len(offs))
-            if want_wave and on_gpu:
-                native.torch_ops().center_rows_(wave)       # the stage loops compare mean-removed outputs (Mic_Array.py:291)
-            elif want_wave:
-                wave -= wave.mean(dim=1, keepdim=True)
-            if on_gpu:
-                e1.record()
-                self.events.append((e0, e1))
-                self.inflight.append(e1)
-            pos = 0
-            for r in group:
-                n = len(r.offs)
-                r.wave = wave[pos:pos + n] if r.want_wave else None
-                r.energy = en[pos:pos + n]
-                r.event = e1 if on_gpu else None
-                pos += n
-            self.launches += 1
-            self.candidates += pos
+            with ctx:
+                self._launch_on_stream(group, key)
         except Exception as exc:                             # every waiting search gets the error
             for r in group:
                 r.error = f"{type(exc).__name__}: {exc}"
         for r in group:
             r.done = True
+
+    def _launch_on_stream(self, group, key):
+        import torch
+        from . import native
+        dev = self.mixes.device
+        offs = np.ascontiguousarray(np.concatenate([r.offs for r in group], axis=0))
+        idx = np.concatenate([np.full(len(r.offs), r.k, dtype=np.int32) for r in group])
+        assert idx.min() >= 0 and idx.max() < self.mixes.shape[0]
+        on_gpu = dev.type == "cuda"                          # (a CPU stand-in model drives this class in the host tests)
+        off_d, idx_d = torch.from_numpy(offs), torch.from_numpy(idx)
+        if on_gpu:
+            off_d = off_d.pin_memory().to(dev, non_blocking=True)
+            idx_d = idx_d.pin_memory().to(dev, non_blocking=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        want_wave = any(r.want_wave for r in group)
+        t_host = time.perf_counter()
+        wave, en = self.model.shift_and_sep_device_multi(self.mixes, off_d, idx_d, key[0], want_wave=want_wave,
+                                                         want_energy=True, window=key[1])
+        self.host_s += time.perf_counter() - t_host
+        self.sizes.append(len(offs))
+        if want_wave and on_gpu:
+            native.torch_ops().center_rows_(wave)           # the stage loops compare mean-removed outputs (Mic_Array.py:291)
+        elif want_wave:
+            wave -= wave.mean(dim=1, keepdim=True)
+        if on_gpu:
+            e1.record()
+            self.events.append((e0, e1))
+            self.inflight.append(e1)
+        pos = 0
+        for r in group:
+            n = len(r.offs)
+            r.wave = wave[pos:pos + n] if r.want_wave else None
+            r.energy = en[pos:pos + n]
+            r.event = e1 if on_gpu else None
+            pos += n
+        self.launches += 1
+        self.candidates += pos
 
 
 class MixtureScorer(object):
@@ -217,7 +253,7 @@ def mixture_view(mic_array):
     return v
 
 
-def search_batched(joint_model, mixes, concurrent=4):
+def search_batched(joint_model, mixes, concurrent=2):
     """The complete localization search (SRP-PHAT -> coarse -> fine -> clustering) of every mixture in
     ``mixes`` on this rank's GPU: ``concurrent`` worker threads pull mixtures from a queue -- a finished
     search is replaced at once, so the GPU never waits for a group to drain -- and score through one
@@ -231,6 +267,7 @@ def search_batched(joint_model, mixes, concurrent=4):
     results = [None] * n
     hosts = [torch.as_tensor(m).to(dtype=torch.float32).cpu() for m in mixes]
     stack = torch.stack(hosts).to(dev).contiguous()          # [K,M,T]: 1.3 MB per 7-mic, 48 000-sample mixture
+    torch.cuda.synchronize(dev)                              # the launch stream reads it
     n_workers = max(1, min(int(concurrent), n))
     batcher = CandidateBatcher(spot, stack, n_workers)
     errors, todo, todo_lock = [], list(range(n)), threading.Lock()
@@ -277,15 +314,25 @@ def search_batched(joint_model, mixes, concurrent=4):
             batcher.worker_done()
             worker_s.append(time.perf_counter() - t_begin)
 
+    # A search alternates short bursts of numpy / Python with blocking device calls (event waits, read-backs); after
+    # each of those it needs the interpreter lock back, and with the default 5 ms switch interval it queues behind
+    # every other search that is in a burst: about 90 ms per request went there (10 blocking calls x 2-3 others x 5 ms),
+    # against 4 ms of host time per request in the single-threaded loop.
+    import sys
+    switch = sys.getswitchinterval()
+    sys.setswitchinterval(min(switch, 2e-4))
     threads = [threading.Thread(target=work, name=f"asw-search-{w}") for w in range(n_workers)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        sys.setswitchinterval(switch)
     if errors:
         raise errors[0]
     torch.cuda.synchronize(dev)
-    stats = {"launches": batcher.launches, "candidates": batcher.candidates, "launch_sizes": list(batcher.sizes),
+    stats = {"launches": batcher.launches, "requests": batcher.requests, "launch_rule": dict(batcher.reasons), "candidates": batcher.candidates, "launch_sizes": list(batcher.sizes),
              "spot_gpu_s": sum(a.elapsed_time(b) for a, b in batcher.events) * 1e-3, "enqueue_host_s": batcher.host_s,
              "wait_pending_s": batcher.wait_pending_s, "wait_device_s": batcher.wait_device_s,
              "worker_s": sum(worker_s), "workers": n_workers}

@@ -279,10 +279,24 @@ int ensure_ws(asw_spot* m, int B, int T, Plan& pl, int lane = 0) {
   layout(m, B, T, dry, pl);
   const size_t need = dry.off + 4096;
   if (need > m->ws_bytes[lane]) {
+    // A workspace that has to grow grows to the model's full internal batch at once: a search issues calls of 30,
+    // then 50 ... 256 candidates, and every growth is a device synchronisation plus a hipFree / hipMalloc of tens of
+    // GB (about 0.2 GB per candidate at T = 48 000) -- 2-3 s each in the kernel trace of the 64-mixture run.
+    size_t want = need;
+    if (B < m->batch) {
+      Plan full;
+      Arena dry_full(nullptr, 0, true);
+      layout(m, m->batch, T, dry_full, full);
+      want = dry_full.off + 4096;
+    }
     if (m->ws[lane]) { ASW_HIP(hipDeviceSynchronize()); (void)hipFree(m->ws[lane]); m->ws[lane] = nullptr; m->ws_bytes[lane] = 0; }
-    if (hipMalloc(&m->ws[lane], need) != hipSuccess)
-      return asw::set_error(ASW_ERR_NOMEM, "workspace of %.1f MiB for batch %d, T=%d", need / 1048576.0, B, T);
-    m->ws_bytes[lane] = need;
+    if (hipMalloc(&m->ws[lane], want) != hipSuccess) {
+      (void)hipGetLastError();
+      want = need;                                         // not enough memory for the full batch: what this call needs
+      if (hipMalloc(&m->ws[lane], want) != hipSuccess)
+        return asw::set_error(ASW_ERR_NOMEM, "workspace of %.1f MiB for batch %d, T=%d", need / 1048576.0, B, T);
+    }
+    m->ws_bytes[lane] = want;
   }
   Arena real(m->ws[lane], m->ws_bytes[lane], false);
   layout(m, B, T, real, pl);

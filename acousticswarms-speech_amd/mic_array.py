@@ -335,7 +335,9 @@ class MicArray(object):
         if n_groups == 0:                                  # a rank that was dealt no coarse patch
             return ([], np.zeros((0, 2))) if owned is not None else []
         if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(device=dev)
+            # high priority: its SI-SDR kernels and read-backs are tiny and sit on the search's critical path, while the
+            # main stream is running whole network launches that fill the device
+            self._side_stream = torch.cuda.Stream(device=dev, priority=-1)
         side, main = self._side_stream, torch.cuda.current_stream(dev)
         # Chunk edges (fractions of the coarse patches).  Only two pieces of host work cannot hide behind
         # the GPU: the subdivision of the first chunk and the clustering of the last one -- so those two

@@ -213,7 +213,7 @@ class ShardedSpotModel:
         return sorted(merged, key=key)
 
 
-def localize_batch(joint_model, mixes, group=None, concurrent=4):
+def localize_batch(joint_model, mixes, group=None, concurrent=2):
     """A batch of mixtures over the ranks of one node (BASELINE config "batch of 64 mixtures"):
     with at least as many mixtures as ranks the cheapest partition is by whole mixture --
     contiguous balanced blocks, each rank runs the complete search of its mixtures on its own

@@ -140,30 +140,32 @@ def test_launch_error_reaches_every_waiting_search():
     assert len(errs) == 2 and all("device fault" in e for e in errs)
 
 
-def test_idle_device_gets_a_part_filled_launch_and_a_busy_one_makes_requests_wait():
-    """the launch rule's device side, driven through the gpu_busy hook: an idle device takes whatever is waiting at
-    once; while it is busy a lone request waits (here: until the poll sees the device idle again)."""
+def test_queue_ahead_rule_launches_until_two_are_in_flight_then_merges():
+    """the launch rule's device side, driven through the inflight hook: with fewer than max_inflight launches queued a
+    lone, part-filled request goes out at once; with two queued the requests wait and are merged when one drains."""
     mixes = torch.zeros(3, 2, 4)
     mixes[:, 0, 0] = torch.arange(1, 4)
     model = _FakeModel()
-    busy = {"v": False}
-    batcher = CandidateBatcher(model, mixes, n_workers=3, target=100, gpu_busy=lambda: busy["v"], poll_s=1e-3)
+    queued = {"n": 0}
+    batcher = CandidateBatcher(model, mixes, n_workers=3, target=100, inflight=lambda: queued["n"], poll_s=1e-3)
     offs = np.ones((2, 1), dtype=np.int32)
     _w, en = batcher.request(0, offs, 0, 12000, False)          # workers 1, 2 never asked, the batch is far from full
     np.testing.assert_array_equal(en.numpy(), _expected(0, offs, 0))
-    assert batcher.launches == 1 and batcher.awaiting == 0
-    busy["v"] = True
+    assert batcher.launches == 1 and batcher.awaiting == 0 and batcher.reasons == {"queue_ahead": 1}
+    queued["n"] = 2
     got = {}
 
-    def requester():
-        _w, e = batcher.request(1, offs, 0, 12000, False)
-        got["en"] = e.numpy()
+    def requester(k):
+        _w, e = batcher.request(k, offs, 0, 12000, False)
+        got[k] = e.numpy()
 
-    t = threading.Thread(target=requester)
-    t.start()
+    ts = [threading.Thread(target=requester, args=(k,)) for k in (1, 2)]
+    [t.start() for t in ts]
     time.sleep(0.05)
-    assert t.is_alive() and batcher.launches == 1               # busy device, others still on the host: it waits
-    busy["v"] = False                                           # the launch in flight drained
-    t.join(timeout=10)
-    assert not t.is_alive() and batcher.launches == 2
-    np.testing.assert_array_equal(got["en"], _expected(1, offs, 0))
+    assert all(t.is_alive() for t in ts) and batcher.launches == 1     # two launches queued on the device: they wait
+    queued["n"] = 1                                             # one drained
+    [t.join(timeout=10) for t in ts]
+    assert not any(t.is_alive() for t in ts) and batcher.launches == 2  # ... and went out together
+    assert model.calls[-1][0] == 4 and model.calls[-1][1] == [1, 2]
+    for k in (1, 2):
+        np.testing.assert_array_equal(got[k], _expected(k, offs, 0))

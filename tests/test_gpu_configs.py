@@ -163,7 +163,14 @@ def test_config3_mixture_batch_equals_plain_loop(full_weights):
         np.testing.assert_array_equal(g[0], w[0])
         np.testing.assert_array_equal(g[1], w[1])
         assert g[2] == w[2] and g[3] == w[3]
-    _log(f"config3: 4 mixtures, talkers {[len(g[2]) for g in got]}, spot calls {[g[3] for g in got]}")
+    # all four searches at once: more requests than the two launches the batcher queues ahead, so some are merged
+    with redirect_stdout(io.StringIO()):
+        four = _batch_summary(localize_batch(jm, mixes, concurrent=4))
+    for g, w in zip(four, want):
+        _same_search_result(g, w)
+    _log(f"config3: 4 mixtures, talkers {[len(g[2]) for g in got]}, spot calls {[g[3] for g in got]}, "
+         f"batcher at 4 searches: {localize_batch.last_stats['launches']} launches for "
+         f"{localize_batch.last_stats['requests']} requests {localize_batch.last_stats['launch_rule']}")
     del jm
     torch.cuda.empty_cache()
     # two ranks (sharing this box's one GPU; gloo carries the object all-gather): mixtures split 2 + 2
