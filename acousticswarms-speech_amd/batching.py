@@ -8,13 +8,13 @@ run concurrently -- one host thread per mixture, each with its own view of the (
 geometry tables -- and every scoring request they make goes through a ``CandidateBatcher``: the
 requests of different mixtures are concatenated into one candidate stream with a per-candidate
 mixture index and evaluated by ONE ``asw_spot_shift_and_sep_multi`` launch sequence, as soon as a
-full internal batch is waiting, the device would otherwise idle, or every live search is stopped
+full internal batch is waiting or fewer than two launches are queued on the device
 (``CandidateBatcher``'s launch rule).  Each search sees
 its own slice of the result, so its decisions are those of the plain per-mixture loop.
 
 Only the spot network's workspace is shared between the searches, and only the batcher touches
-it (under its lock); everything else a search launches (SRP map, SI-SDR matrices) allocates its
-own buffers and runs in stream order on the device's default stream.
+it (under its lock, on the batcher's own stream); everything else a search launches (SRP map,
+SI-SDR matrices) allocates its own buffers and runs on the search's streams.
 """
 import copy
 import threading
