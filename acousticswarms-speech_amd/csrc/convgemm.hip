@@ -564,12 +564,14 @@ void convgemm16_kernel(const asw_convgemm_args p) {
 #define ASW_PIPE_QDB 2
 #endif
 // Main loop of one 256-column tile: picks the tile of this workgroup (false: none, the whole workgroup
-// leaves), runs the K loop and returns the accumulators (wave (wm, wn) of 2 x 4 holds rows
-// wm*BM/2 + 32*i.., columns wn*64 + 32*j..).  Ends on a barrier: the ring is free for the epilogue.
-template <int BM, bool A2F, int BK, int NTERM = 3>
-__device__ __forceinline__ bool pipe_mainloop(const asw_convgemm_args& p, float* smem, floatx16 (&acc)[BM / 64][2],
+// leaves), runs the K loop and returns the accumulators (wave (wm, wn) of WM x 4 holds rows
+// wm*BM/WM + 32*i.., columns wn*64 + 32*j..).  Ends on a barrier: the ring is free for the epilogue.
+// WM = 2: eight waves on a 256-row tile, one workgroup per CU.  WM = 1: four waves on a 128-row tile with the
+// SAME wave tile (128 x 64), two independent workgroups per CU -- one's epilogue under the other's main loop.
+template <int BM, bool A2F, int BK, int NTERM = 3, int WM = 2>
+__device__ __forceinline__ bool pipe_mainloop(const asw_convgemm_args& p, float* smem, floatx16 (&acc)[BM / WM / 32][2],
                                               dim3& tile_out, int& ncol_out) {
-  constexpr int BN = 256, WM = 2, WN = 4, NT = 512, QDB = ASW_PIPE_QDB;
+  constexpr int BN = 256, WN = 4, NT = 64 * WM * WN, QDB = ASW_PIPE_QDB;
   constexpr int LDH = BK + 8, KV = BK / 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_VEC = (BM * KV + NT - 1) / NT;
@@ -707,15 +709,15 @@ __device__ __forceinline__ bool pipe_mainloop(const asw_convgemm_args& p, float*
   return true;
 }
 
-template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32, int NTERM = 3>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
+template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32, int NTERM = 3, int WM = 2>
+__global__ __launch_bounds__(256 * WM) __attribute__((amdgpu_waves_per_eu(2)))
 void convgemm16p_kernel(const asw_convgemm_args p) {
-  constexpr int BN = 256, WM = 2, WN = 4;
+  constexpr int BN = 256, WN = 4;
   extern __shared__ __align__(16) float smem[];
-  floatx16 acc[BM / 64][2];
+  floatx16 acc[BM / WM / 32][2];
   dim3 tile;
   int ncol;
-  if (!pipe_mainloop<BM, A2F, BK, NTERM>(p, smem, acc, tile, ncol)) return;
+  if (!pipe_mainloop<BM, A2F, BK, NTERM, WM>(p, smem, acc, tile, ncol)) return;
   epilogue<BM, BN, WM, WN, false, STATS, false, MUL>(acc, p, smem, __builtin_ldexpf(1.0f, -p.w_shift),
                                                      RowsContig{(int)tile.x * BM, p.M_out}, tile, ncol);
 }
@@ -897,16 +899,17 @@ int launch_mask_path(const asw_maskpath_args* args, void* stream) {
   return ASW_OK;
 }
 
-template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32>
+template <int BM, bool STATS, bool MUL, bool A2F, int BK = 32, int WM = 2>
 int launch_pipe(const asw_convgemm_args& a, hipStream_t s) {
   constexpr int BN = 256;
   constexpr size_t ring = (size_t)2 * 2 * BM * (BK + 8) * sizeof(_Float16);
-  constexpr size_t slab = (size_t)(2 * 32) * (BN + 4) * sizeof(float);
+  constexpr size_t slab = (size_t)(WM * 32) * (BN + 4) * sizeof(float);
   constexpr size_t smem = ring > slab ? ring : slab;
   static_assert(smem <= 160 * 1024, "LDS budget");
+  static_assert(BM == 128 * WM, "wave tile 128 x 64");
   const bool x1 = a.precision == 2;                     // single-pass f16: the one-term instantiation
-  const void* kern = x1 ? reinterpret_cast<const void*>(convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 1>)
-                        : reinterpret_cast<const void*>(convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 3>);
+  const void* kern = x1 ? reinterpret_cast<const void*>(convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 1, WM>)
+                        : reinterpret_cast<const void*>(convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 3, WM>);
   static asw::SmemAttr attr[2];                         // per device and instantiation
   if (int rc = attr[x1].ensure(kern, smem)) return rc;
   ASW_CHECK_ARG(A2F == (a.A2 != nullptr), "convgemm: skip operand variant mismatch");
@@ -920,8 +923,8 @@ int launch_pipe(const asw_convgemm_args& a, hipStream_t s) {
     pn += sh;
   }
   asw::ProfScope prof(s, pn, 2.0 * a.B * (double)a.M_out * a.N * (double)a.taps * a.Cin);
-  if (x1) hipLaunchKernelGGL((convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 1>), grid, dim3(512), smem, s, a);
-  else hipLaunchKernelGGL((convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 3>), grid, dim3(512), smem, s, a);
+  if (x1) hipLaunchKernelGGL((convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 1, WM>), grid, dim3(256 * WM), smem, s, a);
+  else hipLaunchKernelGGL((convgemm16p_kernel<BM, STATS, MUL, A2F, BK, 3, WM>), grid, dim3(256 * WM), smem, s, a);
   ASW_LAUNCH_CHECK();
   return ASW_OK;
 }
@@ -1532,6 +1535,15 @@ extern "C" int asw_convgemm_f32(const asw_convgemm_args* args, void* stream) {
       // (192-row tiles, i.e. a single row tile per item and a long K, stay on the two-barrier kernel:
       // with so little reuse of a weight fragment the global B path loses, 296 vs 322 TFLOP/s)
       if (!no_pipe && a.Wf_hi && a.Wf_lo && t == 2 && (a.taps * a.Cin) % 16 == 0 && a.N % 32 == 0) {
+        // Short K (the decoder's transposed convolutions): two independent 4-wave workgroups of 128 rows per CU, same
+        // wave tile -- one drains its tile while the other computes (K = 512: 234 -> 260 TFLOP/s, K = 256: 186 -> 193;
+        // at K >= 896 and in the mask path the 8-wave tile is 2-4 % ahead).  ASW_PIPE_HALF_TILE=0 / 1 forces one form.
+        static const int force = getenv("ASW_PIPE_HALF_TILE") ? atoi(getenv("ASW_PIPE_HALF_TILE")) : -1;
+        const bool half_tile = force >= 0 ? force == 1 : a.taps * a.Cin <= 512;
+        if (half_tile && !a.mul) {
+          if (stats && a.A2) return launch_pipe<128, true, false, true, 32, 1>(a, s);
+          return stats ? launch_pipe<128, true, false, false, 32, 1>(a, s) : launch_pipe<128, false, false, false, 32, 1>(a, s);
+        }
         if (a.mul) return launch_pipe<256, false, true, false>(a, s);
         if (stats && a.A2) return launch_pipe<256, true, false, true>(a, s);
         return stats ? launch_pipe<256, true, false, false>(a, s) : launch_pipe<256, false, false, false>(a, s);
