@@ -257,10 +257,18 @@ int ensure_ws(asw_sep* m, int NB, int S, int T, Plan& pl) {
   layout(m, NB, S, T, dry, pl);
   const size_t need = dry.off + 4096;
   if (need > m->ws_bytes) {
+    // the number of talkers changes from mixture to mixture: grow by half again, not to the exact size, so that a
+    // stream of mixtures re-allocates (device synchronisation + hipFree / hipMalloc of GBs) a few times, not every
+    // time one more talker than ever before turns up
+    size_t want = need + need / 2;
     if (m->ws) { ASW_HIP(hipDeviceSynchronize()); (void)hipFree(m->ws); m->ws = nullptr; m->ws_bytes = 0; }
-    if (hipMalloc(&m->ws, need) != hipSuccess)
-      return asw::set_error(ASW_ERR_NOMEM, "workspace of %.1f MiB for %d sequences, T=%d", need / 1048576.0, NB * S, T);
-    m->ws_bytes = need;
+    if (hipMalloc(&m->ws, want) != hipSuccess) {
+      (void)hipGetLastError();
+      want = need;
+      if (hipMalloc(&m->ws, want) != hipSuccess)
+        return asw::set_error(ASW_ERR_NOMEM, "workspace of %.1f MiB for %d sequences, T=%d", need / 1048576.0, NB * S, T);
+    }
+    m->ws_bytes = want;
   }
   Arena real(m->ws, m->ws_bytes, false);
   layout(m, NB, S, T, real, pl);
