@@ -109,6 +109,41 @@ def test_wide_and_scaled_operands_f16x3():
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("M,N,K,skip", [(500, 1024, 256, True), (500, 512, 512, True), (500, 512, 1024, False)])
+def test_pipelined_wide_tiles_f16x3(M, N, K, skip):
+    """The 256-column pipelined GEMM (convgemm16p) in both forms -- eight waves on 256 rows (K >= 896) and two 4-wave
+    workgroups of 128 rows per CU (K <= 512, the decoder's transposed convolutions) -- at a batch that fills >= 512
+    tiles, i.e. the shapes the dispatcher sends there: output and GroupNorm partial sums against torch in float64,
+    with the skip operand added on load."""
+    from acousticswarms_speech_amd import ops
+    B = 512 // (2 * (N // 256))                        # two row tiles per item (500 rows: the 256-row form, not 192)
+    x = _rand(B, M, K, seed=31)
+    x2 = _rand(B, M, K, seed=32) if skip else None
+    w = _rand(N, K, seed=33, scale=1 / math.sqrt(K))
+    bias = _rand(N, seed=34, scale=0.1)
+    want = F.linear(((x + x2) if skip else x).double(), w.double(), bias.double())
+    import ctypes
+    import json
+    from acousticswarms_speech_amd import native
+    L = native.lib()
+    L.asw_profile_enable(2)
+    out, st = ops.convgemm(x.cuda(), w.cuda(), M, N, K, bias=bias.cuda(), stats_chan_mod=N,
+                           A2=(x2.cuda() if skip else None), precision="f16x3")
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 16)
+    native.check(L.asw_profile_report(buf, len(buf)))
+    L.asw_profile_enable(0)
+    names = list(json.loads(buf.value.decode()))
+    r = _rel(out.cpu().double(), want)
+    _log(f"pipelined wide tile M={M} N={N} K={K} skip={skip} B={B}: rel={r:.3e} via {names}")
+    assert any(n.startswith("convgemm16p<128," if K <= 512 else "convgemm16p<256,") for n in names), names
+    assert r < 2e-6
+    s = st.cpu().double().sum(1)
+    np.testing.assert_allclose(s[:, 0].numpy(), want[..., :N // 2].sum((1, 2)).numpy(), rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(s[:, 1].numpy(), (want[..., :N // 2] ** 2).sum((1, 2)).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(s[:, 3].numpy(), (want[..., N // 2:] ** 2).sum((1, 2)).numpy(), rtol=1e-5)
+
+
 def _model(cfg, seed, batch=32):
     from acousticswarms_speech_amd.spot import SpotModel
     from acousticswarms_speech_amd.weights import make_spot_state_dict
